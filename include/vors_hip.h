@@ -1,0 +1,200 @@
+/* vors_hip.h — C ABI of the MI355X-native direct RGB-D alignment hot path (libvors_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of mpizenberg/visual-odometry-rs ("vors"): pyramidal
+ * inverse-compositional direct image alignment. Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root). The reference has no FFI today (100 % safe Rust); these
+ * are the symbols a `-sys` style Rust binding would declare (see INTEGRATION.md for the Rust shim).
+ *
+ * Conventions
+ *  - Plain C types only. Caller owns every buffer. No callbacks, no exceptions/aborts across the ABI.
+ *  - Every function returns a vors_status (0 = ok, <0 = error); vors_last_error() gives the message of the last
+ *    error on the calling thread.
+ *  - Handles are NOT thread-safe (one thread per handle, mirroring `&mut self`); distinct handles are independent.
+ *  - Images: gray u8 and depth u16 (TUM scale, 0 = unknown), rows x cols, `layout` = VORS_ROW_MAJOR (decoder order)
+ *    or VORS_COL_MAJOR (nalgebra DMatrix::as_slice(), element (row,col) at col*rows+row).
+ *  - Poses / models: 7 floats  tx ty tz qx qy qz qw  (nalgebra Isometry3<f32>: translation + unit quaternion
+ *    coords [i,j,k,w]; same order as the TUM trajectory line, src/dataset/tum_rgbd.rs:76-86).
+ *  - There is NO CPU fallback: every compute entry point fails with VORS_ERR_NO_DEVICE when no HIP device exists.
+ */
+#ifndef VORS_HIP_H
+#define VORS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vors_status {
+    VORS_OK = 0,
+    VORS_ERR_INVALID_ARGUMENT = -1,
+    VORS_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime error */
+    VORS_ERR_HIP = -3,
+    VORS_ERR_PYRAMID_TOO_SHORT = -4, /* image too small for nb_levels: the reference panics (inverse_compositional.rs:124,183) */
+    VORS_ERR_UNSUPPORTED = -5
+} vors_status;
+
+enum { VORS_ROW_MAJOR = 0, VORS_COL_MAJOR = 1 };
+
+/* Candidate mask source. 0 reproduces the reference (candidates::coarse_to_fine, inverse_compositional.rs:120-125).
+ * 1 = dense: all-true level-0 mask (extension for BASELINE config "dense candidates"; not in the reference). */
+enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1 };
+
+/* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
+enum { VORS_TRACK_OK = 0, VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT = 1 };
+
+/* Replaces `pub struct Config` (src/core/track/inverse_compositional.rs:37-49) with `Intrinsics`
+ * (src/core/camera.rs:84-91) flattened. The last two fields are extensions; zero reproduces the reference. */
+typedef struct vors_config {
+    int32_t nb_levels;                 /* Config::nb_levels */
+    int32_t candidates_diff_threshold; /* Config::candidates_diff_threshold (u16) */
+    float depth_scale;                 /* Config::depth_scale (5000 for TUM, tum_rgbd.rs:15) */
+    float cu, cv;                      /* Intrinsics::principal_point */
+    float fu, fv;                      /* Intrinsics::focal */
+    float skew;                        /* Intrinsics::skew */
+    float idepth_variance;             /* Config::idepth_variance */
+    int32_t candidates_mode;           /* extension: VORS_CANDIDATES_* */
+    float huber_delta;                 /* extension: Huber threshold on |r| in grey levels; <= 0 = plain L2 (reference) */
+} vors_config;
+
+#define VORS_MAX_LEVELS 8
+
+/* Per-pair diagnostics of one track() (none of this exists in the reference API; it is what its commented-out
+ * eprintln!s would show, lm_optimizer.rs:162,171,184, plus the counters the byte model of DESIGN.md needs). */
+typedef struct vors_pair_stats {
+    float lm_model[7];                 /* final lm_model (keyframe camera -> current camera), inverse_compositional.rs:177,193 */
+    float optical_flow;                /* inverse_compositional.rs:213-221 */
+    int32_t change_keyframe;           /* optical_flow >= 1.0 (inverse_compositional.rs:224) */
+    int32_t nb_iter[VORS_MAX_LEVELS];  /* iterations returned by iterative_solve per level (optimizer.rs:57-70); 0 = level not run */
+    int32_t n_points[VORS_MAX_LEVELS]; /* usable candidates per level (extract_z, inverse_compositional.rs:260-279) */
+    float energy[VORS_MAX_LEVELS];     /* energy of the state kept at each level */
+} vors_pair_stats;
+
+const char* vors_last_error(void);
+/* Number of visible HIP devices (0 when none / no runtime). Never fails. */
+int vors_device_count(void);
+/* ABI version of this header: bump on any signature change. */
+int vors_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 1. Tracker: one sequence, host buffers.  Replaces
+ *      Config::init(self, f64, &DMatrix<u16>, f64, DMatrix<u8>) -> Tracker      inverse_compositional.rs:74-100
+ *      Tracker::track(&mut self, f64, &DMatrix<u16>, f64, DMatrix<u8>)           inverse_compositional.rs:170-240
+ *      Tracker::current_frame(&self) -> (f64, Iso3)                              inverse_compositional.rs:243-248
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vors_tracker vors_tracker;
+
+vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const uint16_t* depth, double img_time,
+                                const uint8_t* gray, int rows, int cols, int layout, vors_tracker** out);
+/* Returns VORS_OK and writes the VORS_TRACK_* status of this frame to *track_status (nullable). */
+vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time,
+                               const uint8_t* gray, int* track_status);
+vors_status vors_tracker_current_frame(const vors_tracker* t, double* timestamp, float pose7[7]);
+/* Diagnostics of the last track() and keyframe pose (not in the reference API). */
+vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stats);
+vors_status vors_tracker_keyframe(const vors_tracker* t, double* timestamp, float pose7[7]);
+void vors_tracker_destroy(vors_tracker* t);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 2. Batch of independent frame pairs — the data-parallel hot path. For each pair p:
+ *      tracker = cfg.init(kf_depth[p], kf_gray[p]); tracker.track(cur_gray[p]); pose[p] = tracker.current_frame()
+ *    i.e. vors_track.rs:46-62 for a 2-frame sequence, for n_pairs sequences at once.
+ *    Images of pair p start at offset p*rows*cols. prev_poses7 (nullable) = current_frame_pose before track()
+ *    (identity in the reference's init; the initial guess is its inverse, inverse_compositional.rs:177).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Host buffers (copies in and out; PCIe-inclusive). */
+vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t* kf_gray, const uint16_t* kf_depth,
+                             const uint8_t* cur_gray, int rows, int cols, int layout, const float* prev_poses7,
+                             float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats /* nullable, n_pairs */);
+
+/* Device-resident engine: buffers are DEVICE pointers (row-major), work is enqueued on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised: outputs are valid once the stream
+ * reaches this point. Workspaces are allocated once at create() for up to max_pairs pairs. */
+typedef struct vors_batch vors_batch;
+vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
+vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
+                                   const uint8_t* d_cur_gray, const float* d_prev_poses7 /* nullable */,
+                                   float* d_out_poses7, int32_t* d_out_status,
+                                   vors_pair_stats* d_out_stats /* nullable */, void* hip_stream);
+/* The three stages of the above, separately (keyframe data persists in the handle between calls):
+ *   prepare_keyframes = mean_pyramid + precompute_multires_data        inverse_compositional.rs:83-85,105-161
+ *   track_current     = mean_pyramid + coarse->fine LM + keyframe test  inverse_compositional.rs:177-224 */
+vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
+                                         void* hip_stream);
+vors_status vors_batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
+                                     float* d_out_poses7, int32_t* d_out_status, vors_pair_stats* d_out_stats,
+                                     void* hip_stream);
+/* Bytes of device workspace held by the handle. */
+vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes);
+/* Timing of the dominant kernel (the LM kernel) of the LAST vors_batch_track_* call, measured with HIP events on
+ * hip_stream. Synchronises on those events. ms < 0 when timing was not enabled. */
+vors_status vors_batch_enable_kernel_timing(vors_batch* b, int enable);
+vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms);
+void vors_batch_destroy(vors_batch* b);
+
+/* Inspection of the keyframe data held by a batch handle (device -> host copies; tests and debugging).
+ * level image (mean_pyramid, multires.rs:21-31), row-major rows_l x cols_l: */
+vors_status vors_batch_get_keyframe_image(vors_batch* b, int pair, int level, uint8_t* out, int* rows, int* cols);
+vors_status vors_batch_get_current_image(vors_batch* b, int pair, int level, uint8_t* out, int* rows, int* cols);
+/* usable candidates of a level (extract_z + warp_jacobians, inverse_compositional.rs:260-341): up to `capacity`
+ * points, xy int32[2n], idepth f32[n], jac f32[6n], tmpl u8[n] (all nullable). Order is the device slot order,
+ * NOT the reference's column-major order: sort by (x, y) to compare. *n = number of usable candidates. */
+vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capacity, int32_t* xy, float* idepth, float* jac,
+                                  uint8_t* tmpl, int* n);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 3. Operator level — the optimizer trait's pieces for one pyramid level.  Replaces, for
+ *    `impl optimizer::State<Obs, EvalState, Iso3, String> for LMOptimizerState` (lm_optimizer.rs:111-193):
+ *      vors_lm_eval  = eval_energy + compute_eval_data at a model          lm_optimizer.rs:68-107 (the body of init/eval)
+ *      vors_lm_step  = step()                                              lm_optimizer.rs:123-136
+ *      vors_lm_solve = State::iterative_solve(&obs, model)                 src/math/optimizer.rs:57-70
+ *    vors_obs replaces `pub struct Obs<'a>` (lm_optimizer.rs:43-58); hessians are not passed (J J^T is recomputed).
+ *    Host buffers, row-major images.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vors_obs {
+    float cu, cv, fu, fv, skew; /* Obs::intrinsics (of this level) */
+    int32_t rows, cols;         /* shape of template and image */
+    const uint8_t* template_;   /* Obs::template (keyframe image of this level) */
+    const uint8_t* image;       /* Obs::image (current image of this level) */
+    int32_t n;                  /* number of candidates */
+    const int32_t* coordinates; /* Obs::coordinates: (x, y) pairs, int32[2n] */
+    const float* _z_candidates; /* Obs::_z_candidates: inverse depths, f32[n] */
+    const float* jacobians;     /* Obs::jacobians: f32[6n] */
+    float huber_delta;          /* extension, <= 0 = reference */
+} vors_obs;
+
+vors_status vors_lm_eval(const vors_obs* obs, const float model7[7], float* energy, int32_t* n_inside, float g[6],
+                         float H[36] /* row-major 6x6 */, float* residuals /* nullable f32[n], NaN = outside */);
+/* Host-only arithmetic (6x6 Cholesky + se3::exp + compose + renormalise). *chol_ok = 0 mirrors
+ * Err("Error at Cholesky decomposition of hessian"). */
+vors_status vors_lm_step(const float H[36], const float g[6], const float model7[7], float lm_coef, float out_model7[7],
+                         int* chol_ok);
+/* *solve_status: VORS_TRACK_OK or VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT (step error). */
+vors_status vors_lm_solve(const vors_obs* obs, const float model7[7], float out_model7[7], int32_t* nb_iter, float* energy,
+                          float* lm_coef, int* solve_status);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 4. Lie algebra helpers (host arithmetic; src/math/se3.rs:65-129, src/math/so3.rs:62-99). API parity only:
+ *    the tracker itself only uses se3::exp.
+ * ---------------------------------------------------------------------------------------------------------- */
+void vors_se3_exp(const float xi[6], float out_iso7[7]);
+void vors_se3_log(const float iso7[7], float out_xi[6]);
+void vors_so3_exp(const float w[3], float out_q4[4]);
+void vors_so3_log(const float q4[4], float out_w[3]);
+void vors_iso_mul(const float a7[7], const float b7[7], float out7[7]);
+void vors_iso_inverse(const float a7[7], float out7[7]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 5. Synthetic scene renderer on the device (bench/test tooling). Renders, for pair i in
+ *    [0, n_pairs), the keyframe (identity) and the current frame (exp(xi(seed0+i))) of the textured-plane scene
+ *    into DEVICE buffers, and the ground-truth models (keyframe->current) into d_gt_models7 (nullable).
+ * ---------------------------------------------------------------------------------------------------------- */
+vors_status vors_synth_render_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5],
+                                    double motion_scale, int invalid_percent, uint8_t* d_kf_gray, uint16_t* d_kf_depth,
+                                    uint8_t* d_cur_gray, uint16_t* d_cur_depth /* nullable */, float* d_gt_models7,
+                                    void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORS_HIP_H */

@@ -1,0 +1,708 @@
+// Host engine + extern "C" ABI (include/vors_hip.h) of libvors_hip.so.
+//
+// Owns device workspaces and launches the kernels of kernels.hip. No CPU compute path exists here: every compute
+// entry point needs a HIP device and fails loudly (VORS_ERR_NO_DEVICE) without one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace vors;
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static vors_status fail(vors_status st, const std::string& msg) {
+    g_last_error = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return fail(VORS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                      \
+    } while (0)
+
+static vors_status require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(VORS_ERR_NO_DEVICE, "vors_hip: no HIP device available (this library has no CPU fallback)");
+    }
+    return VORS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------------------------
+static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* g) {
+    if (!cfg) return fail(VORS_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (cfg->nb_levels < 1 || cfg->nb_levels > VORS_MAX_LEVELS)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "nb_levels must be in [1, " + std::to_string(VORS_MAX_LEVELS) + "]");
+    if (rows < 2 || cols < 2 || rows > 65535 || cols > 65535) return fail(VORS_ERR_INVALID_ARGUMENT, "rows/cols must be in [2, 65535]");
+    if (cfg->candidates_mode != VORS_CANDIDATES_COARSE_TO_FINE && cfg->candidates_mode != VORS_CANDIDATES_DENSE)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "unknown candidates_mode");
+    if (cfg->candidates_diff_threshold < 0 || cfg->candidates_diff_threshold > 65535)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "candidates_diff_threshold must fit u16");
+    std::memset(g, 0, sizeof(*g));
+    g->L = cfg->nb_levels;
+    g->mode = cfg->candidates_mode;
+    g->thresh = cfg->candidates_diff_threshold;
+    g->depth_scale = cfg->depth_scale;
+    g->idepth_variance = cfg->idepth_variance;
+    g->huber_delta = cfg->huber_delta;
+    g->S0 = rows * cols;
+    int r = rows, c = cols;
+    Intr k{cfg->cu, cfg->cv, cfg->fu, cfg->fv, cfg->skew};
+    int img_off = 0;
+    for (int l = 0; l < g->L; ++l) {
+        if (l > 0) {
+            r /= 2;  // multires.rs:73-77: halve returns None when a half size is 0
+            c /= 2;
+            if (r == 0 || c == 0)
+                return fail(VORS_ERR_PYRAMID_TOO_SHORT,
+                            "image too small for nb_levels (the reference panics: inverse_compositional.rs:124-125,183-189)");
+            k = intr_half_res(k);  // camera.rs:106-123
+        }
+        g->lv[l].rows = r;
+        g->lv[l].cols = c;
+        g->lv[l].k = k;
+        if (l == 0) {
+            g->lv[l].img_off = -1;
+        } else {
+            g->lv[l].img_off = img_off;
+            img_off += (r * c + 15) & ~15;
+        }
+    }
+    g->upper_stride = std::max(img_off, 16);
+    g->root_rows = g->lv[g->L - 1].rows;
+    g->root_cols = g->lv[g->L - 1].cols;
+    const long n_roots = (long)g->root_rows * g->root_cols;
+    long slot_off = 0;
+    for (int l = 0; l < g->L; ++l) {
+        long n = (g->mode == VORS_CANDIDATES_DENSE) ? (long)g->lv[l].rows * g->lv[l].cols : n_roots * (1L << (g->L - 1 - l));
+        if (slot_off + n > 0x7fffffffL) return fail(VORS_ERR_UNSUPPORTED, "too many candidate slots");
+        g->lv[l].n_slots = (int)n;
+        g->lv[l].slot_off = (int)slot_off;
+        slot_off += (n + 3) & ~3L;
+    }
+    g->slots_total = (int)slot_off;
+    return VORS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident batch engine
+// ---------------------------------------------------------------------------------------------------------------
+struct vors_batch {
+    vors_config cfg;
+    Geom g;
+    int max_pairs = 0;
+    uint8_t* kf_upper = nullptr;
+    uint8_t* cur_upper = nullptr;
+    const uint8_t* kf_level0 = nullptr;   // caller's buffer of the last prepare_keyframes
+    const uint8_t* cur_level0 = nullptr;  // caller's buffer of the last track_current
+    Records rec{};
+    uint64_t bytes = 0;
+    bool timing = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pyr0,pyr1 | kf0,kf1 | lm0,lm1
+    bool ev_valid[3] = {false, false, false};
+    float pyr_ms_accum = 0.f;
+};
+
+template <class T>
+static hipError_t dmalloc(T** p, size_t n, uint64_t* bytes) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+    if (e == hipSuccess) *bytes += n * sizeof(T);
+    return e;
+}
+
+static void batch_free(vors_batch* b) {
+    if (!b) return;
+    if (b->kf_upper) (void)hipFree(b->kf_upper);
+    if (b->cur_upper) (void)hipFree(b->cur_upper);
+    if (b->rec.A) (void)hipFree(b->rec.A);
+    if (b->rec.B) (void)hipFree(b->rec.B);
+    if (b->rec.C) (void)hipFree(b->rec.C);
+    if (b->rec.XY) (void)hipFree(b->rec.XY);
+    if (b->rec.IZ) (void)hipFree(b->rec.IZ);
+    if (b->rec.V) (void)hipFree(b->rec.V);
+    for (auto& e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+extern "C" {
+
+const char* vors_last_error(void) { return g_last_error.c_str(); }
+int vors_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int vors_abi_version(void) { return 1; }
+
+vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
+    if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (max_pairs < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "max_pairs must be >= 1");
+    Geom g;
+    vors_status st = build_geom(cfg, rows, cols, &g);
+    if (st != VORS_OK) return st;
+    if ((st = require_device()) != VORS_OK) return st;
+    vors_batch* b = new vors_batch();
+    b->cfg = *cfg;
+    b->g = g;
+    b->max_pairs = max_pairs;
+    const size_t np = (size_t)max_pairs;
+    const size_t slots = np * (size_t)g.slots_total;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = dmalloc(&b->kf_upper, np * g.upper_stride, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->cur_upper, np * g.upper_stride, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->rec.A, slots, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->rec.B, slots, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->rec.C, slots, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
+    if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
+    if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) e = dmalloc(&b->rec.V, slots, &b->bytes);
+    if (e != hipSuccess) {
+        batch_free(b);
+        return fail(VORS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return VORS_OK;
+}
+
+void vors_batch_destroy(vors_batch* b) { batch_free(b); }
+
+vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes) {
+    if (!b || !bytes) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *bytes = b->bytes;
+    return VORS_OK;
+}
+
+vors_status vors_batch_enable_kernel_timing(vors_batch* b, int enable) {
+    if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (enable && !b->ev[0])
+        for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+    b->timing = enable != 0;
+    return VORS_OK;
+}
+
+static vors_status check_n(const vors_batch* b, int n_pairs) {
+    if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (n_pairs < 1 || n_pairs > b->max_pairs) return fail(VORS_ERR_INVALID_ARGUMENT, "n_pairs out of range for this handle");
+    return VORS_OK;
+}
+
+vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
+                                         void* hip_stream) {
+    vors_status st = check_n(b, n_pairs);
+    if (st != VORS_OK) return st;
+    if (!d_kf_gray || !d_kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL image pointer");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    b->kf_level0 = d_kf_gray;
+    Pyramid kf{d_kf_gray, b->kf_upper};
+    if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], s));
+    launch_pyramid(b->g, kf, n_pairs, s);
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[1], s));
+        HIP_TRY(hipEventRecord(b->ev[2], s));
+    }
+    launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[3], s));
+        b->ev_valid[0] = b->ev_valid[1] = true;
+        b->pyr_ms_accum = -1.f;  // recomputed lazily
+    }
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+// Tracker use: the current frame becomes the keyframe (inverse_compositional.rs:227-239): its pyramid is reused
+// (no recomputation, like the reference's move of img_multires) and only precompute_multires_data runs.
+static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint16_t* d_depth, hipStream_t s) {
+    std::swap(b->kf_upper, b->cur_upper);
+    b->kf_level0 = b->cur_level0;
+    Pyramid kf{b->kf_level0, b->kf_upper};
+    launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
+                                       const float* d_kf_poses7, float* d_out_poses7, int32_t* d_out_status,
+                                       vors_pair_stats* d_out_stats, hipStream_t s) {
+    b->cur_level0 = d_cur_gray;
+    Pyramid cur{d_cur_gray, b->cur_upper};
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (b->timing) {
+        // second pyramid of the pair: timed with its own pair of events created on demand
+        HIP_TRY(hipEventCreate(&p0));
+        HIP_TRY(hipEventCreate(&p1));
+        HIP_TRY(hipEventRecord(p0, s));
+    }
+    launch_pyramid(b->g, cur, n_pairs, s);
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(p1, s));
+        HIP_TRY(hipEventRecord(b->ev[4], s));
+    }
+    launch_lm_track(b->g, cur, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, s);
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[5], s));
+        b->ev_valid[2] = true;
+        HIP_TRY(hipEventSynchronize(p1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p0, p1));
+        b->pyr_ms_accum = ms;
+        (void)hipEventDestroy(p0);
+        (void)hipEventDestroy(p1);
+    }
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+vors_status vors_batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
+                                     float* d_out_poses7, int32_t* d_out_status, vors_pair_stats* d_out_stats,
+                                     void* hip_stream) {
+    vors_status st = check_n(b, n_pairs);
+    if (st != VORS_OK) return st;
+    if (!d_cur_gray || !d_out_poses7 || !d_out_status) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    return batch_track_current(b, n_pairs, d_cur_gray, d_prev_poses7, nullptr, d_out_poses7, d_out_status, d_out_stats,
+                               static_cast<hipStream_t>(hip_stream));
+}
+
+vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
+                                   const uint8_t* d_cur_gray, const float* d_prev_poses7, float* d_out_poses7,
+                                   int32_t* d_out_status, vors_pair_stats* d_out_stats, void* hip_stream) {
+    vors_status st = vors_batch_prepare_keyframes(b, n_pairs, d_kf_gray, d_kf_depth, hip_stream);
+    if (st != VORS_OK) return st;
+    return vors_batch_track_current(b, n_pairs, d_cur_gray, d_prev_poses7, d_out_poses7, d_out_status, d_out_stats, hip_stream);
+}
+
+vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms) {
+    if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    float lm = -1.f, kf = -1.f, py = -1.f;
+    if (b->timing) {
+        if (b->ev_valid[2]) {
+            HIP_TRY(hipEventSynchronize(b->ev[5]));
+            HIP_TRY(hipEventElapsedTime(&lm, b->ev[4], b->ev[5]));
+        }
+        if (b->ev_valid[1]) {
+            HIP_TRY(hipEventSynchronize(b->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&kf, b->ev[2], b->ev[3]));
+        }
+        if (b->ev_valid[0]) {
+            HIP_TRY(hipEventSynchronize(b->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&py, b->ev[0], b->ev[1]));
+            if (b->pyr_ms_accum >= 0.f) py += b->pyr_ms_accum;
+        }
+    }
+    if (lm_ms) *lm_ms = lm;
+    if (keyframe_ms) *keyframe_ms = kf;
+    if (pyramid_ms) *pyramid_ms = py;
+    return VORS_OK;
+}
+
+static vors_status get_image(vors_batch* b, const uint8_t* level0, const uint8_t* upper, int pair, int level, uint8_t* out,
+                             int* rows, int* cols) {
+    if (!b || !out) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
+    if (!level0) return fail(VORS_ERR_INVALID_ARGUMENT, "no image has been submitted yet");
+    const LevelGeom& lg = b->g.lv[level];
+    const uint8_t* src = level == 0 ? level0 + (size_t)pair * b->g.S0 : upper + (size_t)pair * b->g.upper_stride + lg.img_off;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, src, (size_t)lg.rows * lg.cols, hipMemcpyDeviceToHost));
+    if (rows) *rows = lg.rows;
+    if (cols) *cols = lg.cols;
+    return VORS_OK;
+}
+vors_status vors_batch_get_keyframe_image(vors_batch* b, int pair, int level, uint8_t* out, int* rows, int* cols) {
+    return get_image(b, b ? b->kf_level0 : nullptr, b ? b->kf_upper : nullptr, pair, level, out, rows, cols);
+}
+vors_status vors_batch_get_current_image(vors_batch* b, int pair, int level, uint8_t* out, int* rows, int* cols) {
+    return get_image(b, b ? b->cur_level0 : nullptr, b ? b->cur_upper : nullptr, pair, level, out, rows, cols);
+}
+
+vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capacity, int32_t* xy, float* idepth, float* jac,
+                                  uint8_t* tmpl, int* n_out) {
+    if (!b || !n_out) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
+    const LevelGeom& lg = b->g.lv[level];
+    const size_t base = (size_t)pair * b->g.slots_total + lg.slot_off;
+    const size_t n = (size_t)lg.n_slots;
+    std::vector<float4> A(n), B(n);
+    std::vector<float2> C(n);
+    std::vector<uint32_t> XY(n);
+    std::vector<float> IZ(n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(A.data(), b->rec.A + base, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(B.data(), b->rec.B + base, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(C.data(), b->rec.C + base, n * sizeof(float2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(XY.data(), b->rec.XY + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(IZ.data(), b->rec.IZ + base, n * sizeof(float), hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!(A[i].w >= 0.f)) continue;
+        if (cnt < capacity) {
+            if (xy) {
+                xy[2 * cnt] = (int32_t)(XY[i] & 0xffffu);
+                xy[2 * cnt + 1] = (int32_t)(XY[i] >> 16);
+            }
+            if (idepth) idepth[cnt] = IZ[i];
+            if (jac) {
+                jac[6 * cnt] = B[i].x; jac[6 * cnt + 1] = B[i].y; jac[6 * cnt + 2] = B[i].z; jac[6 * cnt + 3] = B[i].w;
+                jac[6 * cnt + 4] = C[i].x; jac[6 * cnt + 5] = C[i].y;
+            }
+            if (tmpl) tmpl[cnt] = (uint8_t)A[i].w;
+        }
+        ++cnt;
+    }
+    *n_out = cnt;
+    return VORS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-buffer batch entry
+// ---------------------------------------------------------------------------------------------------------------
+// Upload an image batch and convert to the row-major device layout when the caller's layout is column-major.
+static vors_status upload_u8(const uint8_t* host, int n, int rows, int cols, int layout, DevBuf& dst, DevBuf& tmp, hipStream_t s) {
+    const size_t bytes = (size_t)n * rows * cols;
+    if (layout == VORS_ROW_MAJOR) {
+        HIP_TRY(hipMemcpyAsync(dst.p, host, bytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(tmp.p, host, bytes, hipMemcpyHostToDevice, s));
+        launch_transpose_u8(tmp.as<uint8_t>(), dst.as<uint8_t>(), rows, cols, n, s);
+    }
+    return VORS_OK;
+}
+static vors_status upload_u16(const uint16_t* host, int n, int rows, int cols, int layout, DevBuf& dst, DevBuf& tmp, hipStream_t s) {
+    const size_t bytes = (size_t)n * rows * cols * 2;
+    if (layout == VORS_ROW_MAJOR) {
+        HIP_TRY(hipMemcpyAsync(dst.p, host, bytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(tmp.p, host, bytes, hipMemcpyHostToDevice, s));
+        launch_transpose_u16(tmp.as<uint16_t>(), dst.as<uint16_t>(), rows, cols, n, s);
+    }
+    return VORS_OK;
+}
+
+vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t* kf_gray, const uint16_t* kf_depth,
+                             const uint8_t* cur_gray, int rows, int cols, int layout, const float* prev_poses7,
+                             float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats) {
+    if (!kf_gray || !kf_depth || !cur_gray || !out_poses7 || !out_status) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    if (layout != VORS_ROW_MAJOR && layout != VORS_COL_MAJOR) return fail(VORS_ERR_INVALID_ARGUMENT, "bad layout");
+    if (n_pairs < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "n_pairs must be >= 1");
+    vors_batch* b = nullptr;
+    vors_status st = vors_batch_create(cfg, n_pairs, rows, cols, &b);
+    if (st != VORS_OK) return st;
+    struct Guard {
+        vors_batch* b;
+        ~Guard() { vors_batch_destroy(b); }
+    } guard{b};
+    const size_t S = (size_t)rows * cols, n = (size_t)n_pairs;
+    DevBuf d_kf, d_dep, d_cur, d_tmp, d_prev, d_pose, d_stat, d_stats;
+    HIP_TRY(d_kf.alloc(n * S));
+    HIP_TRY(d_dep.alloc(n * S * 2));
+    HIP_TRY(d_cur.alloc(n * S));
+    if (layout == VORS_COL_MAJOR) HIP_TRY(d_tmp.alloc(n * S * 2));
+    HIP_TRY(d_pose.alloc(n * 7 * sizeof(float)));
+    HIP_TRY(d_stat.alloc(n * sizeof(int32_t)));
+    HIP_TRY(d_stats.alloc(n * sizeof(vors_pair_stats)));
+    hipStream_t s = nullptr;
+    if ((st = upload_u8(kf_gray, n_pairs, rows, cols, layout, d_kf, d_tmp, s)) != VORS_OK) return st;
+    if ((st = upload_u16(kf_depth, n_pairs, rows, cols, layout, d_dep, d_tmp, s)) != VORS_OK) return st;
+    if ((st = upload_u8(cur_gray, n_pairs, rows, cols, layout, d_cur, d_tmp, s)) != VORS_OK) return st;
+    if (prev_poses7) {
+        HIP_TRY(d_prev.alloc(n * 7 * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_prev.p, prev_poses7, n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    st = vors_batch_track_pairs(b, n_pairs, d_kf.as<uint8_t>(), d_dep.as<uint16_t>(), d_cur.as<uint8_t>(),
+                                prev_poses7 ? d_prev.as<float>() : nullptr, d_pose.as<float>(), d_stat.as<int32_t>(),
+                                d_stats.as<vors_pair_stats>(), s);
+    if (st != VORS_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out_poses7, d_pose.p, n * 7 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_status, d_stat.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out_stats) HIP_TRY(hipMemcpyAsync(out_stats, d_stats.p, n * sizeof(vors_pair_stats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VORS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tracker: one sequence (Config::init / Tracker::track / Tracker::current_frame)
+// ---------------------------------------------------------------------------------------------------------------
+struct vors_tracker {
+    vors_config cfg;
+    int rows = 0, cols = 0, layout = 0;
+    vors_batch* batch = nullptr;
+    DevBuf gray[2];  // [kf_slot] = keyframe level 0, [1 - kf_slot] = current level 0
+    int kf_slot = 0;
+    DevBuf depth, tmp, poses /* prev(7) kf(7) out(7) */, status, stats;
+    // State of inverse_compositional.rs:52-60
+    double keyframe_depth_timestamp = 0, keyframe_img_timestamp = 0;
+    Iso keyframe_pose = iso_identity();
+    double current_frame_depth_timestamp = 0, current_frame_img_timestamp = 0;
+    Iso current_frame_pose = iso_identity();
+    vors_pair_stats last{};
+    bool has_last = false;
+    ~vors_tracker() { vors_batch_destroy(batch); }
+};
+
+extern "C" {
+
+vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const uint16_t* depth, double img_time,
+                                const uint8_t* gray, int rows, int cols, int layout, vors_tracker** out) {
+    if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL image pointer");
+    if (layout != VORS_ROW_MAJOR && layout != VORS_COL_MAJOR) return fail(VORS_ERR_INVALID_ARGUMENT, "bad layout");
+    vors_batch* b = nullptr;
+    vors_status st = vors_batch_create(cfg, 1, rows, cols, &b);
+    if (st != VORS_OK) return st;
+    vors_tracker* t = new vors_tracker();
+    t->batch = b;
+    t->cfg = *cfg;
+    t->rows = rows;
+    t->cols = cols;
+    t->layout = layout;
+    struct Guard {
+        vors_tracker* t;
+        ~Guard() { delete t; }
+    } guard{t};
+    const size_t S = (size_t)rows * cols;
+    HIP_TRY(t->gray[0].alloc(S));
+    HIP_TRY(t->gray[1].alloc(S));
+    HIP_TRY(t->depth.alloc(S * 2));
+    HIP_TRY(t->tmp.alloc(S * 2));
+    HIP_TRY(t->poses.alloc(21 * sizeof(float)));
+    HIP_TRY(t->status.alloc(sizeof(int32_t)));
+    HIP_TRY(t->stats.alloc(sizeof(vors_pair_stats)));
+    hipStream_t s = nullptr;
+    if ((st = upload_u8(gray, 1, rows, cols, layout, t->gray[0], t->tmp, s)) != VORS_OK) return st;
+    if ((st = upload_u16(depth, 1, rows, cols, layout, t->depth, t->tmp, s)) != VORS_OK) return st;
+    st = vors_batch_prepare_keyframes(b, 1, t->gray[0].as<uint8_t>(), t->depth.as<uint16_t>(), s);
+    if (st != VORS_OK) return st;
+    HIP_TRY(hipStreamSynchronize(s));
+    t->kf_slot = 0;
+    t->keyframe_depth_timestamp = depth_time;
+    t->keyframe_img_timestamp = img_time;
+    t->current_frame_depth_timestamp = depth_time;
+    t->current_frame_img_timestamp = img_time;
+    guard.t = nullptr;
+    *out = t;
+    return VORS_OK;
+}
+
+vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
+                               int* track_status) {
+    if (!t || !depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    hipStream_t s = nullptr;
+    const int cur_slot = 1 - t->kf_slot;
+    vors_status st = upload_u8(gray, 1, t->rows, t->cols, t->layout, t->gray[cur_slot], t->tmp, s);
+    if (st != VORS_OK) return st;
+    float h_poses[14];
+    iso_store(t->current_frame_pose, h_poses);
+    iso_store(t->keyframe_pose, h_poses + 7);
+    HIP_TRY(hipMemcpyAsync(t->poses.p, h_poses, sizeof(h_poses), hipMemcpyHostToDevice, s));
+    float* dp = t->poses.as<float>();
+    st = batch_track_current(t->batch, 1, t->gray[cur_slot].as<uint8_t>(), dp, dp + 7, dp + 14, t->status.as<int32_t>(),
+                             t->stats.as<vors_pair_stats>(), s);
+    if (st != VORS_OK) return st;
+    float h_out[7];
+    int32_t h_status = 0;
+    HIP_TRY(hipMemcpyAsync(h_out, dp + 14, sizeof(h_out), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_status, t->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&t->last, t->stats.p, sizeof(vors_pair_stats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    t->has_last = true;
+    // inverse_compositional.rs:203-208
+    t->current_frame_depth_timestamp = depth_time;
+    t->current_frame_img_timestamp = img_time;
+    t->current_frame_pose = iso_load(h_out);  // == previous pose when the optimizer failed
+    // inverse_compositional.rs:224-239
+    if (t->last.change_keyframe) {
+        st = upload_u16(depth, 1, t->rows, t->cols, t->layout, t->depth, t->tmp, s);
+        if (st != VORS_OK) return st;
+        st = batch_promote_current(t->batch, 1, t->depth.as<uint16_t>(), s);
+        if (st != VORS_OK) return st;
+        HIP_TRY(hipStreamSynchronize(s));
+        t->kf_slot = cur_slot;
+        t->keyframe_depth_timestamp = depth_time;
+        t->keyframe_img_timestamp = img_time;
+        t->keyframe_pose = t->current_frame_pose;
+    }
+    if (track_status) *track_status = h_status;
+    return VORS_OK;
+}
+
+vors_status vors_tracker_current_frame(const vors_tracker* t, double* timestamp, float pose7[7]) {
+    if (!t || !timestamp || !pose7) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *timestamp = t->current_frame_depth_timestamp;  // the DEPTH timestamp: inverse_compositional.rs:243-247
+    iso_store(t->current_frame_pose, pose7);
+    return VORS_OK;
+}
+vors_status vors_tracker_keyframe(const vors_tracker* t, double* timestamp, float pose7[7]) {
+    if (!t || !timestamp || !pose7) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *timestamp = t->keyframe_depth_timestamp;
+    iso_store(t->keyframe_pose, pose7);
+    return VORS_OK;
+}
+vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stats) {
+    if (!t || !stats) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!t->has_last) return fail(VORS_ERR_INVALID_ARGUMENT, "no frame has been tracked yet");
+    *stats = t->last;
+    return VORS_OK;
+}
+void vors_tracker_destroy(vors_tracker* t) { delete t; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// operator level
+// ---------------------------------------------------------------------------------------------------------------
+struct ObsDev {
+    DevBuf tmpl, img, xy, iz, jac, A, B, C, XY, IZ, model, out, res;
+    Records rec{};
+    Intr k;
+};
+static vors_status upload_obs(const vors_obs* o, const float model7[7], ObsDev& d, bool want_res, hipStream_t s) {
+    if (!o || !model7) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (o->rows < 2 || o->cols < 2 || o->n < 0) return fail(VORS_ERR_INVALID_ARGUMENT, "bad observation shape");
+    if (!o->template_ || !o->image || (o->n > 0 && (!o->coordinates || !o->_z_candidates || !o->jacobians)))
+        return fail(VORS_ERR_INVALID_ARGUMENT, "NULL observation array");
+    vors_status st = require_device();
+    if (st != VORS_OK) return st;
+    const size_t S = (size_t)o->rows * o->cols, n = (size_t)o->n;
+    for (size_t i = 0; i < n; ++i) {
+        const int x = o->coordinates[2 * i], y = o->coordinates[2 * i + 1];
+        if (x < 0 || y < 0 || x >= o->cols || y >= o->rows) return fail(VORS_ERR_INVALID_ARGUMENT, "coordinate outside the template");
+    }
+    HIP_TRY(d.tmpl.alloc(S));
+    HIP_TRY(d.img.alloc(S));
+    HIP_TRY(d.xy.alloc(n * 8));
+    HIP_TRY(d.iz.alloc(n * 4));
+    HIP_TRY(d.jac.alloc(n * 24));
+    HIP_TRY(d.A.alloc(n * 16));
+    HIP_TRY(d.B.alloc(n * 16));
+    HIP_TRY(d.C.alloc(n * 8));
+    HIP_TRY(d.XY.alloc(n * 4));
+    HIP_TRY(d.IZ.alloc(n * 4));
+    HIP_TRY(d.model.alloc(7 * 4));
+    HIP_TRY(d.out.alloc(64 * 4));
+    if (want_res) HIP_TRY(d.res.alloc(n * 4));
+    HIP_TRY(hipMemcpyAsync(d.tmpl.p, o->template_, S, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d.img.p, o->image, S, hipMemcpyHostToDevice, s));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d.xy.p, o->coordinates, n * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d.iz.p, o->_z_candidates, n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d.jac.p, o->jacobians, n * 24, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemcpyAsync(d.model.p, model7, 28, hipMemcpyHostToDevice, s));
+    d.k = Intr{o->cu, o->cv, o->fu, o->fv, o->skew};
+    d.rec = Records{d.A.as<float4>(), d.B.as<float4>(), d.C.as<float2>(), d.XY.as<uint32_t>(), d.IZ.as<float>(), nullptr};
+    launch_records_from_obs(d.k, o->rows, o->cols, d.tmpl.as<uint8_t>(), o->n, d.xy.as<int32_t>(), d.iz.as<float>(),
+                            d.jac.as<float>(), d.rec, s);
+    return VORS_OK;
+}
+
+vors_status vors_lm_eval(const vors_obs* obs, const float model7[7], float* energy, int32_t* n_inside, float g[6], float H[36],
+                         float* residuals) {
+    if (!energy || !n_inside || !g || !H) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL output");
+    ObsDev d;
+    hipStream_t s = nullptr;
+    vors_status st = upload_obs(obs, model7, d, residuals != nullptr, s);
+    if (st != VORS_OK) return st;
+    launch_lm_eval_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                       d.out.as<float>(), residuals ? d.res.as<float>() : nullptr, s);
+    float out[44];
+    HIP_TRY(hipMemcpyAsync(out, d.out.p, sizeof(out), hipMemcpyDeviceToHost, s));
+    if (residuals && obs->n) HIP_TRY(hipMemcpyAsync(residuals, d.res.p, (size_t)obs->n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    *energy = out[0];
+    *n_inside = (int32_t)out[1];
+    std::memcpy(g, out + 2, 24);
+    std::memcpy(H, out + 8, 144);
+    return VORS_OK;
+}
+
+vors_status vors_lm_solve(const vors_obs* obs, const float model7[7], float out_model7[7], int32_t* nb_iter, float* energy,
+                          float* lm_coef, int* solve_status) {
+    if (!out_model7 || !nb_iter || !energy || !lm_coef || !solve_status) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL output");
+    ObsDev d;
+    hipStream_t s = nullptr;
+    vors_status st = upload_obs(obs, model7, d, false, s);
+    if (st != VORS_OK) return st;
+    launch_lm_solve_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                        d.out.as<float>(), s);
+    float out[11];
+    HIP_TRY(hipMemcpyAsync(out, d.out.p, sizeof(out), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    std::memcpy(out_model7, out, 28);
+    *nb_iter = (int32_t)out[7];
+    *energy = out[8];
+    *lm_coef = out[9];
+    *solve_status = out[10] != 0.f ? VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT : VORS_TRACK_OK;
+    return VORS_OK;
+}
+
+vors_status vors_lm_step(const float H[36], const float g[6], const float model7[7], float lm_coef, float out_model7[7],
+                         int* chol_ok) {
+    if (!H || !g || !model7 || !out_model7 || !chol_ok) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    Iso out;
+    const bool ok = lm_step(H, g, iso_load(model7), lm_coef, &out);
+    *chol_ok = ok ? 1 : 0;
+    if (ok) iso_store(out, out_model7);
+    return VORS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lie helpers (host arithmetic)
+// ---------------------------------------------------------------------------------------------------------------
+void vors_se3_exp(const float xi[6], float out_iso7[7]) { iso_store(se3_exp(xi), out_iso7); }
+void vors_se3_log(const float iso7[7], float out_xi[6]) { se3_log(iso_load(iso7), out_xi); }
+void vors_so3_exp(const float w[3], float out_q4[4]) {
+    const Quat q = so3_exp(w);
+    out_q4[0] = q.i; out_q4[1] = q.j; out_q4[2] = q.k; out_q4[3] = q.w;
+}
+void vors_so3_log(const float q4[4], float out_w[3]) { so3_log(Quat{q4[0], q4[1], q4[2], q4[3]}, out_w); }
+void vors_iso_mul(const float a7[7], const float b7[7], float out7[7]) { iso_store(iso_mul(iso_load(a7), iso_load(b7)), out7); }
+void vors_iso_inverse(const float a7[7], float out7[7]) { iso_store(iso_inverse(iso_load(a7)), out7); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthetic scenes
+// ---------------------------------------------------------------------------------------------------------------
+vors_status vors_synth_render_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5], double motion_scale,
+                                    int invalid_percent, uint8_t* d_kf_gray, uint16_t* d_kf_depth, uint8_t* d_cur_gray,
+                                    uint16_t* d_cur_depth, float* d_gt_models7, void* hip_stream) {
+    if (!cam5 || !d_kf_gray || !d_kf_depth || !d_cur_gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_pairs < 1 || rows < 1 || cols < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "bad shape");
+    vors_status st = require_device();
+    if (st != VORS_OK) return st;
+    launch_synth_pairs(seed0, n_pairs, rows, cols, cam5, motion_scale, invalid_percent, d_kf_gray, d_kf_depth, d_cur_gray,
+                       d_cur_depth, d_gt_models7, static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Internal interface between the HIP kernels (kernels_*.hip) and the host engine / C ABI (capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vors_hip.h"
+#include "lie.h"
+
+namespace vors {
+
+// Geometry of one pyramid level.
+struct LevelGeom {
+    int rows, cols;     // image shape at this level (floor halving, multires.rs:67-88)
+    int img_off;        // byte offset of this level inside the per-pair "upper levels" buffer (levels >= 1); -1 for level 0
+    int n_slots;        // candidate slots at this level (sparse: roots * 2^(L-1-l); dense: rows*cols)
+    int slot_off;       // offset of this level's slots inside the per-pair record planes
+    Intr k;             // intrinsics of this level (camera.rs:106-123)
+};
+
+// Everything a kernel needs to know about the batch layout. Passed by value.
+struct Geom {
+    int L;              // nb_levels
+    int mode;           // VORS_CANDIDATES_*
+    int thresh;         // candidates_diff_threshold (u16)
+    float depth_scale, idepth_variance, huber_delta;
+    int S0;             // rows*cols of level 0 (pair stride of level-0 images and depth maps)
+    int upper_stride;   // bytes per pair of levels 1..L-1
+    int slots_total;    // record slots per pair (all levels)
+    int root_rows, root_cols;  // shape of the coarsest level (= roots of the selection quad-trees)
+    LevelGeom lv[VORS_MAX_LEVELS];
+};
+
+// Candidate record planes (structure of arrays, one entry per slot; pair stride = slots_total):
+//   A = (X, Y, Z, tmpl)  back-projected keyframe point (camera.rs:135-140) + template grey level; tmpl < 0 = empty slot
+//   B = (J0, J1, J2, J3) C = (J4, J5)   warp Jacobian (inverse_compositional.rs:313-341)
+//   XY = x | y << 16     pixel coordinates (keyframe test, inspection)
+//   IZ = inverse depth   (inspection only)
+struct Records {
+    float4* A;
+    float4* B;
+    float2* C;
+    uint32_t* XY;
+    float* IZ;
+    float* V;  // dense mode only: fused weight ("variance") plane, < 0 = Unknown
+};
+
+// Image pyramid of a batch: level 0 is the caller's buffer (zero copy), levels >= 1 live in `upper`.
+struct Pyramid {
+    const uint8_t* level0;  // pair stride S0
+    uint8_t* upper;         // pair stride upper_stride
+};
+
+void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
+void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
+void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
+void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
+void launch_lm_track(const Geom& g, Pyramid cur, Records rec, const float* prev_poses7, const float* kf_poses7,
+                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, hipStream_t s);
+// Operator level on explicit observations of one level (device buffers): eval at `model` -> out29 partial sums layout:
+// [0]=sum r^2 (or Huber loss), [1]=n_inside (as float), [2..7]=g, [8..28]=H upper triangle row-wise.
+void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
+                        const float* model7, float* out_energy_n_g_h /* 44 floats: e, n, g6, H36 */, float* residuals,
+                        hipStream_t s);
+void launch_lm_solve_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
+                         const float* model7, float* out /* model7, nb_iter, energy, lm_coef, status */, hipStream_t s);
+// Records from explicit (x, y, idepth, jac, template) arrays: operator-level entry.
+void launch_records_from_obs(Intr k, int rows, int cols, const uint8_t* tmpl, int n, const int32_t* xy, const float* iz,
+                             const float* jac, Records rec, hipStream_t s);
+void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5], double motion_scale,
+                        int invalid_percent, uint8_t* kf_gray, uint16_t* kf_depth, uint8_t* cur_gray, uint16_t* cur_depth,
+                        float* gt_models7, hipStream_t s);
+
+}  // namespace vors
