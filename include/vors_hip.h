@@ -126,9 +126,13 @@ vors_status vors_batch_track_current(vors_batch* b, int n_pairs, const uint8_t* 
                                      void* hip_stream);
 /* Bytes of device workspace held by the handle. */
 vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes);
-/* Timing of the dominant kernel (the LM kernel) of the LAST vors_batch_track_* call, measured with HIP events on
- * hip_stream. Synchronises on those events. ms < 0 when timing was not enabled. */
-vors_status vors_batch_enable_kernel_timing(vors_batch* b, int enable);
+/* Per-stage kernel timing with HIP events recorded on hip_stream (non-blocking during a step).
+ * ring = number of most recent steps kept per stage (0 disables). Stages: 0 keyframe pyramid, 1 keyframe
+ * precompute, 2 current pyramid, 3 LM kernel (the dominant one). kernel_times() synchronises on the events it reads
+ * and returns the durations (ms) of the last min(steps, ring) steps, oldest first. */
+vors_status vors_batch_enable_kernel_timing(vors_batch* b, int ring);
+vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int capacity, int* n_out);
+/* Most recent step only; pyramid_ms = keyframe + current pyramids; a value < 0 = not measured. */
 vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms);
 void vors_batch_destroy(vors_batch* b);
 

@@ -110,10 +110,11 @@ struct vors_batch {
     const uint8_t* cur_level0 = nullptr;  // caller's buffer of the last track_current
     Records rec{};
     uint64_t bytes = 0;
-    bool timing = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pyr0,pyr1 | kf0,kf1 | lm0,lm1
-    bool ev_valid[3] = {false, false, false};
-    float pyr_ms_accum = 0.f;
+    // Per-stage HIP-event ring (stage: 0 keyframe pyramid, 1 keyframe precompute, 2 current pyramid, 3 LM kernel).
+    // Events are only RECORDED on the caller's stream during a step (non-blocking); elapsed times are read afterwards.
+    int ring = 0;
+    std::vector<hipEvent_t> ev0[4], ev1[4];
+    long count[4] = {0, 0, 0, 0};
 };
 
 template <class T>
@@ -133,8 +134,10 @@ static void batch_free(vors_batch* b) {
     if (b->rec.XY) (void)hipFree(b->rec.XY);
     if (b->rec.IZ) (void)hipFree(b->rec.IZ);
     if (b->rec.V) (void)hipFree(b->rec.V);
-    for (auto& e : b->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (int st = 0; st < 4; ++st) {
+        for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
+        for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
+    }
     delete b;
 }
 
@@ -147,6 +150,18 @@ struct DevBuf {
     template <class T>
     T* as() { return static_cast<T*>(p); }
 };
+
+#define STAGE_BEGIN(b, st, s) \
+    do {                      \
+        if ((b)->ring > 0) HIP_TRY(hipEventRecord((b)->ev0[st][(b)->count[st] % (b)->ring], s)); \
+    } while (0)
+#define STAGE_END(b, st, s)   \
+    do {                      \
+        if ((b)->ring > 0) {  \
+            HIP_TRY(hipEventRecord((b)->ev1[st][(b)->count[st] % (b)->ring], s)); \
+            (b)->count[st] += 1; \
+        }                     \
+    } while (0)
 
 extern "C" {
 
@@ -200,11 +215,21 @@ vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes) {
     return VORS_OK;
 }
 
-vors_status vors_batch_enable_kernel_timing(vors_batch* b, int enable) {
+vors_status vors_batch_enable_kernel_timing(vors_batch* b, int ring) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
-    if (enable && !b->ev[0])
-        for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
-    b->timing = enable != 0;
+    if (ring < 0 || ring > 4096) return fail(VORS_ERR_INVALID_ARGUMENT, "ring must be in [0, 4096]");
+    for (int st = 0; st < 4; ++st) {
+        for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
+        for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
+        b->ev0[st].assign(ring, nullptr);
+        b->ev1[st].assign(ring, nullptr);
+        b->count[st] = 0;
+        for (int k = 0; k < ring; ++k) {
+            HIP_TRY(hipEventCreate(&b->ev0[st][k]));
+            HIP_TRY(hipEventCreate(&b->ev1[st][k]));
+        }
+    }
+    b->ring = ring;
     return VORS_OK;
 }
 
@@ -222,18 +247,12 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     b->kf_level0 = d_kf_gray;
     Pyramid kf{d_kf_gray, b->kf_upper};
-    if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], s));
+    STAGE_BEGIN(b, 0, s);
     launch_pyramid(b->g, kf, n_pairs, s);
-    if (b->timing) {
-        HIP_TRY(hipEventRecord(b->ev[1], s));
-        HIP_TRY(hipEventRecord(b->ev[2], s));
-    }
+    STAGE_END(b, 0, s);
+    STAGE_BEGIN(b, 1, s);
     launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
-    if (b->timing) {
-        HIP_TRY(hipEventRecord(b->ev[3], s));
-        b->ev_valid[0] = b->ev_valid[1] = true;
-        b->pyr_ms_accum = -1.f;  // recomputed lazily
-    }
+    STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
 }
@@ -244,7 +263,9 @@ static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint1
     std::swap(b->kf_upper, b->cur_upper);
     b->kf_level0 = b->cur_level0;
     Pyramid kf{b->kf_level0, b->kf_upper};
+    STAGE_BEGIN(b, 1, s);
     launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
+    STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
 }
@@ -254,29 +275,12 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
                                        vors_pair_stats* d_out_stats, hipStream_t s) {
     b->cur_level0 = d_cur_gray;
     Pyramid cur{d_cur_gray, b->cur_upper};
-    hipEvent_t p0 = nullptr, p1 = nullptr;
-    if (b->timing) {
-        // second pyramid of the pair: timed with its own pair of events created on demand
-        HIP_TRY(hipEventCreate(&p0));
-        HIP_TRY(hipEventCreate(&p1));
-        HIP_TRY(hipEventRecord(p0, s));
-    }
+    STAGE_BEGIN(b, 2, s);
     launch_pyramid(b->g, cur, n_pairs, s);
-    if (b->timing) {
-        HIP_TRY(hipEventRecord(p1, s));
-        HIP_TRY(hipEventRecord(b->ev[4], s));
-    }
+    STAGE_END(b, 2, s);
+    STAGE_BEGIN(b, 3, s);
     launch_lm_track(b->g, cur, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, s);
-    if (b->timing) {
-        HIP_TRY(hipEventRecord(b->ev[5], s));
-        b->ev_valid[2] = true;
-        HIP_TRY(hipEventSynchronize(p1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, p0, p1));
-        b->pyr_ms_accum = ms;
-        (void)hipEventDestroy(p0);
-        (void)hipEventDestroy(p1);
-    }
+    STAGE_END(b, 3, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
 }
@@ -299,27 +303,31 @@ vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_
     return vors_batch_track_current(b, n_pairs, d_cur_gray, d_prev_poses7, d_out_poses7, d_out_status, d_out_stats, hip_stream);
 }
 
+vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int capacity, int* n_out) {
+    if (!b || !n_out || stage < 0 || stage > 3) return fail(VORS_ERR_INVALID_ARGUMENT, "bad argument");
+    const int n = (int)std::min<long>(b->count[stage], b->ring);
+    *n_out = n;
+    for (int k = 0; k < n && k < capacity; ++k) {
+        // oldest first
+        const long idx = (b->count[stage] - n + k) % b->ring;
+        HIP_TRY(hipEventSynchronize(b->ev1[stage][idx]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[k], b->ev0[stage][idx], b->ev1[stage][idx]));
+    }
+    return VORS_OK;
+}
+
 vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
-    float lm = -1.f, kf = -1.f, py = -1.f;
-    if (b->timing) {
-        if (b->ev_valid[2]) {
-            HIP_TRY(hipEventSynchronize(b->ev[5]));
-            HIP_TRY(hipEventElapsedTime(&lm, b->ev[4], b->ev[5]));
+    float v[4] = {-1.f, -1.f, -1.f, -1.f};
+    for (int st = 0; st < 4; ++st)
+        if (b->ring > 0 && b->count[st] > 0) {
+            const long idx = (b->count[st] - 1) % b->ring;
+            HIP_TRY(hipEventSynchronize(b->ev1[st][idx]));
+            HIP_TRY(hipEventElapsedTime(&v[st], b->ev0[st][idx], b->ev1[st][idx]));
         }
-        if (b->ev_valid[1]) {
-            HIP_TRY(hipEventSynchronize(b->ev[3]));
-            HIP_TRY(hipEventElapsedTime(&kf, b->ev[2], b->ev[3]));
-        }
-        if (b->ev_valid[0]) {
-            HIP_TRY(hipEventSynchronize(b->ev[1]));
-            HIP_TRY(hipEventElapsedTime(&py, b->ev[0], b->ev[1]));
-            if (b->pyr_ms_accum >= 0.f) py += b->pyr_ms_accum;
-        }
-    }
-    if (lm_ms) *lm_ms = lm;
-    if (keyframe_ms) *keyframe_ms = kf;
-    if (pyramid_ms) *pyramid_ms = py;
+    if (lm_ms) *lm_ms = v[3];
+    if (keyframe_ms) *keyframe_ms = v[1];
+    if (pyramid_ms) *pyramid_ms = (v[0] < 0.f && v[2] < 0.f) ? -1.f : std::max(v[0], 0.f) + std::max(v[2], 0.f);
     return VORS_OK;
 }
 

@@ -90,7 +90,8 @@ EXPORTED_SYMBOLS = [
     "vors_tracker_keyframe", "vors_tracker_destroy",
     "vors_track_pairs",
     "vors_batch_create", "vors_batch_track_pairs", "vors_batch_prepare_keyframes", "vors_batch_track_current",
-    "vors_batch_workspace_bytes", "vors_batch_enable_kernel_timing", "vors_batch_last_kernel_ms", "vors_batch_destroy",
+    "vors_batch_workspace_bytes", "vors_batch_enable_kernel_timing", "vors_batch_kernel_times", "vors_batch_last_kernel_ms",
+    "vors_batch_destroy",
     "vors_batch_get_keyframe_image", "vors_batch_get_current_image", "vors_batch_get_points",
     "vors_lm_eval", "vors_lm_step", "vors_lm_solve",
     "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
@@ -124,6 +125,7 @@ def lib():
         _lib.vors_batch_track_current.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
         _lib.vors_batch_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
         _lib.vors_batch_enable_kernel_timing.argtypes = [vp, i]
+        _lib.vors_batch_kernel_times.argtypes = [vp, i, vp, i, C.POINTER(i)]
         _lib.vors_batch_last_kernel_ms.argtypes = [vp, C.POINTER(f), C.POINTER(f), C.POINTER(f)]
         _lib.vors_batch_destroy.argtypes = [vp]
         _lib.vors_batch_destroy.restype = None
@@ -213,8 +215,11 @@ class Tracker:
                                          C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().vors_tracker_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vors_tracker_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def track(self, depth_time, depth_map, img_time, img):
@@ -273,8 +278,11 @@ class Batch:
         _check(lib().vors_batch_create(C.byref(cfg), max_pairs, rows, cols, C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().vors_batch_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vors_batch_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     @staticmethod
@@ -291,8 +299,17 @@ class Batch:
         _check(lib().vors_batch_workspace_bytes(self._h, C.byref(b)))
         return b.value
 
-    def enable_kernel_timing(self, enable=True):
-        _check(lib().vors_batch_enable_kernel_timing(self._h, int(enable)))
+    def enable_kernel_timing(self, ring=64):
+        _check(lib().vors_batch_enable_kernel_timing(self._h, int(ring)))
+
+    STAGES = {"pyramid_keyframe": 0, "keyframe": 1, "pyramid_current": 2, "lm": 3}
+
+    def kernel_times(self, stage):
+        """Durations (ms) of the last min(steps, ring) steps of a stage, oldest first (HIP events on the stream)."""
+        out = np.zeros(4096, np.float32)
+        n = C.c_int()
+        _check(lib().vors_batch_kernel_times(self._h, self.STAGES[stage], _ptr(out), 4096, C.byref(n)))
+        return out[:n.value].copy()
 
     def last_kernel_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
