@@ -27,6 +27,6 @@ def test_oracle_reproduces_golden(path):
 
 
 def test_synthetic_generator_is_deterministic():
-    g = np.load(GOLDEN[0])
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sparse_128x96_L4.npz"))
     kg, kd, cg, cd, gt = O.synth_pair(0x5EED1000, int(g["rows"]), int(g["cols"]), tuple(g["intr"]))
     assert (kg == g["kf_gray"][0]).all() and (kd == g["kf_depth"][0]).all() and (cg == g["cur_gray"][0]).all()
