@@ -80,11 +80,12 @@ class Workload:
 
 def timed_run(work, steps, warmup, world, gathered):
     import torch.distributed as dist
+    from vors_amd.distributed import gather_poses
 
     def one():
         work.step()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, work.poses)  # the single RCCL gather of poses
+            gather_poses(work.poses, out=gathered)  # the single RCCL all-gather of poses
 
     for _ in range(warmup):
         one()

@@ -936,6 +936,8 @@ struct Tracker {  // inverse_compositional.rs:31-34 + 52-60
         const MultiresData& keyframe_data = keyframe_multires_data;
         bool optimization_went_well = true;
         last_level_stats.assign(config.nb_levels, LevelStats());
+        for (size_t l = 0; l < config.nb_levels; ++l)
+            last_level_stats[l].n_points = (int)keyframe_data.usable_candidates_multires[l].second.size();
         last_error.clear();
         for (int lvl = (int)config.nb_levels - 1; lvl >= 0; --lvl) {
             lm_optimizer::Obs obs;
@@ -950,7 +952,6 @@ struct Tracker {  // inverse_compositional.rs:31-34 + 52-60
             lm_optimizer::LMOptimizerState lm_state;
             size_t nb_iter = 0;
             std::string err;
-            last_level_stats[lvl].n_points = (int)obs.coordinates->size();
             if (lm_optimizer::LMOptimizerState::iterative_solve(obs, lm_model, lm_state, nb_iter, err)) {
                 lm_model = lm_state.eval_data.model;
                 last_level_stats[lvl].nb_iter = (int)nb_iter;
