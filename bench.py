@@ -34,7 +34,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--pairs", type=int, default=256, help="frame pairs per GPU per step (SURVEY.md §8d config 2: 256)")
+    p.add_argument("--pairs", type=int, default=1024,
+                   help="frame pairs per GPU per step (weak scaling). 1024 keeps 4 workgroup-waves of pairs per CU in flight; "
+                        "SURVEY.md §8d's 256 (one pair per CU) is latency-bound: see DESIGN.md §7")
     p.add_argument("--candidates", choices=["dense", "c2f"], default="dense",
                    help="dense = BASELINE configs[1] (extension); c2f = the reference's coarse-to-fine selection")
     p.add_argument("--rows", type=int, default=480)

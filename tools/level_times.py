@@ -1,0 +1,25 @@
+"""Per-level time of the LM kernel (needs the VORS_PROFILE_LEVELS build: libvors_hip_prof.so). Development aid."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
+import numpy as np, torch
+import vors_amd as V
+V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", "libvors_hip_prof.so")
+from oracle import oracle as O
+rows, cols, L = 480, 640, 6
+intr = O.scaled_intrinsics(rows, cols)
+n = int(os.environ.get("PAIRS", "256"))
+kg, kd, cg, _, gt = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
+poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(n)
+for mode in (0, 1):
+    for blk in (256, 1024):
+        os.environ["VORS_LM_BLOCK"] = str(blk)
+        b = V.Batch(V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode), n, rows, cols)
+        b.enable_kernel_timing(4)
+        for _ in range(3): b.track_pairs(kg, kd, cg, poses, status, stats)
+        torch.cuda.synchronize()
+        st = V.decode_stats(stats)
+        us = st["energy"][:, :L]
+        it = st["nb_iter"][:, :L]
+        print(f"mode {mode} block {blk}: lm kernel {b.kernel_times('lm')[-1]*1e3:.0f} us; per-level mean us {np.round(us.mean(0),1)} max {np.round(us.max(0),1)}; "
+              f"mean evals {np.round((it+1).mean(0),1)}; sum-of-levels mean {us.sum(1).mean():.0f} max {us.sum(1).max():.0f}; us/eval {np.round(us.mean(0)/(it+1).mean(0),2)}")

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,14 +87,19 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     g->root_cols = g->lv[g->L - 1].cols;
     const long n_roots = (long)g->root_rows * g->root_cols;
     long slot_off = 0;
+    const bool dense = g->mode == VORS_CANDIDATES_DENSE;
     for (int l = 0; l < g->L; ++l) {
-        long n = (g->mode == VORS_CANDIDATES_DENSE) ? (long)g->lv[l].rows * g->lv[l].cols : n_roots * (1L << (g->L - 1 - l));
+        long n = dense ? (long)g->lv[l].rows * g->lv[l].cols : n_roots * (1L << (g->L - 1 - l));
         if (slot_off + n > 0x7fffffffL) return fail(VORS_ERR_UNSUPPORTED, "too many candidate slots");
         g->lv[l].n_slots = (int)n;
+        if (dense && l == 0) {  // dense level 0 stores nothing per point (recomputed on the fly by the LM kernel)
+            g->lv[l].slot_off = -1;
+            continue;
+        }
         g->lv[l].slot_off = (int)slot_off;
         slot_off += (n + 3) & ~3L;
     }
-    g->slots_total = (int)slot_off;
+    g->slots_total = (int)std::max(slot_off, 4L);
     return VORS_OK;
 }
 
@@ -108,8 +114,10 @@ struct vors_batch {
     uint8_t* cur_upper = nullptr;
     const uint8_t* kf_level0 = nullptr;   // caller's buffer of the last prepare_keyframes
     const uint8_t* cur_level0 = nullptr;  // caller's buffer of the last track_current
+    const uint16_t* kf_depth = nullptr;   // caller's depth buffer of the last prepare_keyframes (read by the dense LM kernel)
     Records rec{};
     uint64_t bytes = 0;
+    int lm_block = 256;  // threads per frame pair in the LM kernel (256 / 512 / 1024)
     // Per-stage HIP-event ring (stage: 0 keyframe pyramid, 1 keyframe precompute, 2 current pyramid, 3 LM kernel).
     // Events are only RECORDED on the caller's stream during a step (non-blocking); elapsed times are read afterwards.
     int ring = 0;
@@ -188,17 +196,23 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     b->cfg = *cfg;
     b->g = g;
     b->max_pairs = max_pairs;
+    b->lm_block = 1024;
+    if (const char* e = getenv("VORS_LM_BLOCK")) b->lm_block = atoi(e);  // tuning knob (256 / 512 / 1024)
     const size_t np = (size_t)max_pairs;
     const size_t slots = np * (size_t)g.slots_total;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = dmalloc(&b->kf_upper, np * g.upper_stride, &b->bytes);
     if (e == hipSuccess) e = dmalloc(&b->cur_upper, np * g.upper_stride, &b->bytes);
-    if (e == hipSuccess) e = dmalloc(&b->rec.A, slots, &b->bytes);
-    if (e == hipSuccess) e = dmalloc(&b->rec.B, slots, &b->bytes);
-    if (e == hipSuccess) e = dmalloc(&b->rec.C, slots, &b->bytes);
-    if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
-    if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
-    if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) e = dmalloc(&b->rec.V, slots, &b->bytes);
+    if (g.mode == VORS_CANDIDATES_DENSE) {
+        if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.V, slots, &b->bytes);
+    } else {
+        if (e == hipSuccess) e = dmalloc(&b->rec.A, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.B, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.C, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
+    }
     if (e != hipSuccess) {
         batch_free(b);
         return fail(VORS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -246,6 +260,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     if (!d_kf_gray || !d_kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL image pointer");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     b->kf_level0 = d_kf_gray;
+    b->kf_depth = d_kf_depth;
     Pyramid kf{d_kf_gray, b->kf_upper};
     STAGE_BEGIN(b, 0, s);
     launch_pyramid(b->g, kf, n_pairs, s);
@@ -262,6 +277,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
 static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint16_t* d_depth, hipStream_t s) {
     std::swap(b->kf_upper, b->cur_upper);
     b->kf_level0 = b->cur_level0;
+    b->kf_depth = d_depth;
     Pyramid kf{b->kf_level0, b->kf_upper};
     STAGE_BEGIN(b, 1, s);
     launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
@@ -273,13 +289,14 @@ static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint1
 static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
                                        const float* d_kf_poses7, float* d_out_poses7, int32_t* d_out_status,
                                        vors_pair_stats* d_out_stats, hipStream_t s) {
+    if (!b->kf_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "track_current called before prepare_keyframes");
     b->cur_level0 = d_cur_gray;
     Pyramid cur{d_cur_gray, b->cur_upper};
     STAGE_BEGIN(b, 2, s);
     launch_pyramid(b->g, cur, n_pairs, s);
     STAGE_END(b, 2, s);
     STAGE_BEGIN(b, 3, s);
-    launch_lm_track(b->g, cur, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, s);
+    launch_lm_track(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, b->lm_block, s);
     STAGE_END(b, 3, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -356,18 +373,37 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     if (!b || !n_out) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     const LevelGeom& lg = b->g.lv[level];
-    const size_t base = (size_t)pair * b->g.slots_total + lg.slot_off;
     const size_t n = (size_t)lg.n_slots;
     std::vector<float4> A(n), B(n);
     std::vector<float2> C(n);
     std::vector<uint32_t> XY(n);
     std::vector<float> IZ(n);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(A.data(), b->rec.A + base, n * sizeof(float4), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(B.data(), b->rec.B + base, n * sizeof(float4), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(C.data(), b->rec.C + base, n * sizeof(float2), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(XY.data(), b->rec.XY + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(IZ.data(), b->rec.IZ + base, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (b->g.mode == VORS_CANDIDATES_DENSE) {
+        // dense mode keeps no per-point records: materialise this level with the LM kernel's own arithmetic
+        if (!b->kf_level0 || !b->kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "no keyframe has been prepared yet");
+        DevBuf dA, dB, dC, dXY, dIZ;
+        HIP_TRY(dA.alloc(n * 16));
+        HIP_TRY(dB.alloc(n * 16));
+        HIP_TRY(dC.alloc(n * 8));
+        HIP_TRY(dXY.alloc(n * 4));
+        HIP_TRY(dIZ.alloc(n * 4));
+        Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr};
+        launch_dense_materialize(b->g, level, pair, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, out, nullptr);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(A.data(), dA.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(B.data(), dB.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(C.data(), dC.p, n * sizeof(float2), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(XY.data(), dXY.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(IZ.data(), dIZ.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        const size_t base = (size_t)pair * b->g.slots_total + lg.slot_off;
+        HIP_TRY(hipMemcpy(A.data(), b->rec.A + base, n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(B.data(), b->rec.B + base, n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(C.data(), b->rec.C + base, n * sizeof(float2), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(XY.data(), b->rec.XY + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(IZ.data(), b->rec.IZ + base, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
     int cnt = 0;
     for (size_t i = 0; i < n; ++i) {
         if (!(A[i].w >= 0.f)) continue;

@@ -1,0 +1,43 @@
+// Device helpers shared by kernels.hip and lm_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "engine.h"
+
+namespace vors {
+
+#define VORS_INVALID_XY 0xFFFFFFFFu
+
+// ------------------------------------------------------------------------------------------------------------
+// image helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint8_t* level_ptr(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l) {
+    return l == 0 ? level0 + (size_t)pair * g.S0 : upper + (size_t)pair * g.upper_stride + g.lv[l].img_off;
+}
+
+// Gradient at level l, pixel (x, y), of the pyramid (level0, upper):
+//  l == 0: centred difference, truncating /2, 1-px border = 0                      gradient.rs:15-33
+//  l >= 1: 2x2 block gradient of the next finer level (a c / b d), truncating /2   gradient.rs:74-93, multires.rs:112-126
+__device__ __forceinline__ void grad_at(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l, int x,
+                                        int y, int* gx, int* gy) {
+    if (l == 0) {
+        const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+        if (x == 0 || y == 0 || x == cols - 1 || y == rows - 1) {
+            *gx = 0;
+            *gy = 0;
+            return;
+        }
+        const uint8_t* p = level0 + (size_t)pair * g.S0 + (size_t)y * cols + x;
+        *gx = ((int)p[1] - (int)p[-1]) / 2;
+        *gy = ((int)p[cols] - (int)p[-cols]) / 2;
+    } else {
+        const int fc = g.lv[l - 1].cols;
+        const uint8_t* p = level_ptr(g, level0, upper, pair, l - 1) + (size_t)(2 * y) * fc + 2 * x;
+        const int a = p[0], c = p[1], b = p[fc], d = p[fc + 1];
+        *gx = (c + d - a - b) / 2;
+        *gy = (b - a + d - c) / 2;
+    }
+}
+
+
+}  // namespace vors

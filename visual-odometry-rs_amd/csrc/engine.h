@@ -13,7 +13,7 @@ struct LevelGeom {
     int rows, cols;     // image shape at this level (floor halving, multires.rs:67-88)
     int img_off;        // byte offset of this level inside the per-pair "upper levels" buffer (levels >= 1); -1 for level 0
     int n_slots;        // candidate slots at this level (sparse: roots * 2^(L-1-l); dense: rows*cols)
-    int slot_off;       // offset of this level's slots inside the per-pair record planes
+    int slot_off;       // offset of this level's slots inside the per-pair planes (dense: IZ/V planes hold levels >= 1 only; -1 for level 0)
     Intr k;             // intrinsics of this level (camera.rs:106-123)
 };
 
@@ -54,8 +54,11 @@ void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int
 void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
-void launch_lm_track(const Geom& g, Pyramid cur, Records rec, const float* prev_poses7, const float* kf_poses7,
-                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, hipStream_t s);
+void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
+                              hipStream_t s);
+// `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).
+void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
+                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, hipStream_t s);
 // Operator level on explicit observations of one level (device buffers): eval at `model` -> out29 partial sums layout:
 // [0]=sum r^2 (or Huber loss), [1]=n_inside (as float), [2..7]=g, [8..28]=H upper triangle row-wise.
 void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,

@@ -15,43 +15,11 @@
 // Where fusing is harmless (accumulating the sums) explicit fmaf is used.
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "engine.h"
 #include "synth_scene.h"
 
 namespace vors {
-
-#define VORS_INVALID_XY 0xFFFFFFFFu
-
-// ------------------------------------------------------------------------------------------------------------
-// image helpers
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ const uint8_t* level_ptr(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l) {
-    return l == 0 ? level0 + (size_t)pair * g.S0 : upper + (size_t)pair * g.upper_stride + g.lv[l].img_off;
-}
-
-// Gradient at level l, pixel (x, y), of the pyramid (level0, upper):
-//  l == 0: centred difference, truncating /2, 1-px border = 0                      gradient.rs:15-33
-//  l >= 1: 2x2 block gradient of the next finer level (a c / b d), truncating /2   gradient.rs:74-93, multires.rs:112-126
-__device__ __forceinline__ void grad_at(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l, int x,
-                                        int y, int* gx, int* gy) {
-    if (l == 0) {
-        const int rows = g.lv[0].rows, cols = g.lv[0].cols;
-        if (x == 0 || y == 0 || x == cols - 1 || y == rows - 1) {
-            *gx = 0;
-            *gy = 0;
-            return;
-        }
-        const uint8_t* p = level0 + (size_t)pair * g.S0 + (size_t)y * cols + x;
-        *gx = ((int)p[1] - (int)p[-1]) / 2;
-        *gy = ((int)p[cols] - (int)p[-cols]) / 2;
-    } else {
-        const int fc = g.lv[l - 1].cols;
-        const uint8_t* p = level_ptr(g, level0, upper, pair, l - 1) + (size_t)(2 * y) * fc + 2 * x;
-        const int a = p[0], c = p[1], b = p[fc], d = p[fc + 1];
-        *gx = (c + d - a - b) / 2;
-        *gy = (b - a + d - c) / 2;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // layout conversion (column-major DMatrix::as_slice() -> row-major device layout)
@@ -303,18 +271,60 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// keyframe precompute, dense candidates (extension): all-true level-0 mask, any image size. Slots are the pixels
-// (slot = y*cols + x at each level). The inverse-depth pyramid is built level by level in the IZ / V planes,
-// fusing the four children in [a,b,c,d] order (inverse_depth.rs:49-66,81-98); V < 0 marks Unknown.
+// keyframe precompute, dense candidates (extension): all-true level-0 mask, any image size. Candidates are the pixels
+// themselves (slot = y*cols + x at each level). NOTHING per-point is stored for level 0: the LM kernel recomputes each
+// point from the keyframe image and the depth map (lm_kernels.hip, DenseSrc). For levels >= 1 only the fused inverse depth
+// (IZ plane, NaN = Unknown) and its weight (V plane, < 0 = Unknown) are stored: 8 B per pixel of levels >= 1.
+// Fusion follows inverse_depth.rs:49-66,81-98 with the four children in [a,b,c,d] order.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dense_idepth_level0_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
+__device__ __forceinline__ void fuse_dso_mean(const float dv_in[4], const float vv_in[4], float* od, float* ov) {
+    float dv[4], vv[4];
+    int n = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (vv_in[m] >= 0.f) {
+            dv[n] = dv_in[m];
+            vv[n] = vv_in[m];
+            ++n;
+        }
+    *od = __builtin_nanf("");
+    *ov = -1.0f;
+    if (n == 1) {
+        *od = dv[0];
+        *ov = vv[0];
+    } else if (n == 2) {
+        *ov = vv[0] + vv[1];
+        *od = (dv[0] * vv[0] + dv[1] * vv[1]) / *ov;
+    } else if (n == 3) {
+        *ov = vv[0] + vv[1] + vv[2];
+        *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2]) / *ov;
+    } else if (n == 4) {
+        *ov = vv[0] + vv[1] + vv[2] + vv[3];
+        *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2] + dv[3] * vv[3]) / *ov;
+    }
+}
+// level 1 straight from the depth map (from_depth, inverse_depth.rs:24-29, fused with the first halve)
+__global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     const int pair = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.lv[0].n_slots) return;
-    const size_t slot = (size_t)pair * g.slots_total + g.lv[0].slot_off + t;
-    const uint16_t dz = depth[(size_t)pair * g.S0 + t];
-    rec.IZ[slot] = dz != 0 ? g.depth_scale / (float)dz : 0.f;  // inverse_depth.rs:24-29
-    rec.V[slot] = dz != 0 ? g.idepth_variance : -1.0f;
+    const int rows = g.lv[1].rows, cols = g.lv[1].cols;
+    if (t >= rows * cols) return;
+    const int y = t / cols, x = t - y * cols;
+    const int fc = g.lv[0].cols;
+    const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x;
+    // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1) with i=row, j=col   (multires.rs:80-83)
+    const uint16_t dz[4] = {p[0], p[fc], p[1], p[fc + 1]};
+    float dv[4], vv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+        vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
+    }
+    float od, ov;
+    fuse_dso_mean(dv, vv, &od, &ov);
+    const size_t slot = (size_t)pair * g.slots_total + g.lv[1].slot_off + t;
+    rec.IZ[slot] = od;
+    rec.V[slot] = ov;
 }
 __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, Records rec) {
     const int pair = blockIdx.y;
@@ -324,439 +334,63 @@ __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, 
     const int y = t / cols, x = t - y * cols;
     const int fc = g.lv[l - 1].cols;
     const size_t cb = (size_t)pair * g.slots_total + g.lv[l - 1].slot_off + (size_t)(2 * y) * fc + 2 * x;
-    // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1) with i=row, j=col   (multires.rs:80-83)
     const size_t idx[4] = {cb, cb + fc, cb + 1, cb + fc + 1};
     float dv[4], vv[4];
-    int n = 0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float v = rec.V[idx[m]];
-        if (v >= 0.f) {
-            dv[n] = rec.IZ[idx[m]];
-            vv[n] = v;
-            ++n;
-        }
+        dv[m] = rec.IZ[idx[m]];
+        vv[m] = rec.V[idx[m]];
     }
-    float od = 0.f, ov = -1.0f;
-    if (n == 1) {
-        od = dv[0];
-        ov = vv[0];
-    } else if (n == 2) {
-        ov = vv[0] + vv[1];
-        od = (dv[0] * vv[0] + dv[1] * vv[1]) / ov;
-    } else if (n == 3) {
-        ov = vv[0] + vv[1] + vv[2];
-        od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2]) / ov;
-    } else if (n == 4) {
-        ov = vv[0] + vv[1] + vv[2] + vv[3];
-        od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2] + dv[3] * vv[3]) / ov;
-    }
+    float od, ov;
+    fuse_dso_mean(dv, vv, &od, &ov);
     const size_t slot = (size_t)pair * g.slots_total + g.lv[l].slot_off + t;
     rec.IZ[slot] = od;
     rec.V[slot] = ov;
 }
-__global__ __launch_bounds__(256) void dense_records_kernel(Geom g, int l, const uint8_t* __restrict__ kf0,
-                                                             const uint8_t* __restrict__ kfu, Records rec) {
-    const int pair = blockIdx.y;
+// Inspection only (vors_batch_get_points in dense mode): materialise the records of ONE level of ONE pair into `out`
+// (planes of n_slots entries, index = y*cols + x), with exactly the arithmetic the LM kernel uses on the fly.
+__global__ __launch_bounds__(256) void dense_materialize_kernel(Geom g, int l, int pair, const uint8_t* __restrict__ kf0,
+                                                                 const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ depth,
+                                                                 Records rec, Records out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[l].rows, cols = g.lv[l].cols;
     if (t >= rows * cols) return;
     const int y = t / cols, x = t - y * cols;
-    const size_t slot = (size_t)pair * g.slots_total + g.lv[l].slot_off + t;
-    if (rec.V[slot] >= 0.f) {
+    float iz;
+    bool valid;
+    if (l == 0) {
+        const uint16_t dz = depth[(size_t)pair * g.S0 + t];
+        valid = dz != 0;
+        iz = g.depth_scale / (float)dz;
+    } else {
+        iz = rec.IZ[(size_t)pair * g.slots_total + g.lv[l].slot_off + t];
+        valid = !(iz != iz);
+    }
+    if (valid) {
         int gx, gy;
         grad_at(g, kf0, kfu, pair, l, x, y, &gx, &gy);
-        write_record(rec, slot, g.lv[l].k, x, y, rec.IZ[slot], gx, gy, level_ptr(g, kf0, kfu, pair, l)[t]);
+        write_record(out, t, g.lv[l].k, x, y, iz, gx, gy, level_ptr(g, kf0, kfu, pair, l)[t]);
     } else {
-        write_empty(rec, slot);
+        write_empty(out, t);
     }
+}
+void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(dense_materialize_kernel, dim3((g.lv[l].n_slots + 255) / 256), dim3(256), 0, s, g, l, pair, kf.level0, kf.upper,
+                       depth, rec, out);
 }
 
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
     const int n_roots = g.root_rows * g.root_cols;
     if (g.mode == VORS_CANDIDATES_DENSE) {
-        hipLaunchKernelGGL(dense_idepth_level0_kernel, dim3((g.lv[0].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
-        for (int l = 1; l < g.L; ++l)
+        if (g.L >= 2)
+            hipLaunchKernelGGL(dense_idepth_level1_kernel, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+        for (int l = 2; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
-        for (int l = 0; l < g.L; ++l)
-            hipLaunchKernelGGL(dense_records_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, kf.level0,
-                               kf.upper, rec);
     } else {
         dim3 grid((n_roots + KF_WAVES - 1) / KF_WAVES, n_pairs);
         hipLaunchKernelGGL(keyframe_sparse_kernel, grid, dim3(64 * KF_WAVES), 0, s, g, kf.level0, kf.upper, depth, rec);
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// LM evaluation: eval_energy + compute_eval_data fused in ONE pass (lm_optimizer.rs:68-107).
-// Per valid slot: warp (lm_optimizer.rs:213-219), bilinear interpolation with the reference's strict inside test
-// (lm_optimizer.rs:227-251), residual r = I(w(x)) - T(x), then 29 partial sums: sum r^2, count, g = sum J r (6),
-// H = sum J J^T (21 unique). J J^T is recomputed from J instead of streaming the reference's precomputed 6x6.
-// ------------------------------------------------------------------------------------------------------------
-#define NACC 29
-
-struct EvalCtx {
-    const uint8_t* img;  // current image of this level, row-major
-    int rows, cols;
-    Intr k;
-    const float4* A;
-    const float4* B;
-    const float2* C;
-    int n_slots;
-    float huber;
-};
-
-template <int BLOCK, bool WRITE_RES>
-__device__ __forceinline__ void eval_accumulate(const EvalCtx& c, const Iso& model, float acc[NACC], float* residuals) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
-    const float wm2 = (float)(c.cols - 2), hm2 = (float)(c.rows - 2);
-    for (int i = threadIdx.x; i < c.n_slots; i += BLOCK) {
-        const float4 a = c.A[i];
-        float res = __builtin_nanf("");
-        if (a.w >= 0.f) {
-            const V3 p2 = iso_transform_point(model, V3{a.x, a.y, a.z});
-            float u, v;
-            project_uv(c.k, p2, &u, &v);
-            const float uf = floorf(u), vf = floorf(v);
-            if (uf >= 0.f && uf < wm2 && vf >= 0.f && vf < hm2) {
-                const int u0 = (int)uf, v0 = (int)vf;
-                const uint8_t* p = c.img + (size_t)v0 * c.cols + u0;
-                const float vu_00 = (float)p[0], vu_01 = (float)p[1];
-                const float vu_10 = (float)p[c.cols], vu_11 = (float)p[c.cols + 1];
-                const float fa = u - uf, fb = v - vf;
-                const float im = (1.0f - fb) * (1.0f - fa) * vu_00 + fb * (1.0f - fa) * vu_10 + (1.0f - fb) * fa * vu_01 +
-                                 fb * fa * vu_11;
-                const float r = im - a.w;
-                res = r;
-                const float4 jb = c.B[i];
-                const float2 jc = c.C[i];
-                const float J[6] = {jb.x, jb.y, jb.z, jb.w, jc.x, jc.y};
-                float w = 1.0f, wr = r;
-                if (c.huber > 0.f) {  // extension (not in the reference)
-                    const float ar = fabsf(r);
-                    if (ar <= c.huber) {
-                        acc[0] = fmaf(r, r, acc[0]);
-                    } else {
-                        acc[0] += c.huber * (2.0f * ar - c.huber);
-                        w = c.huber / ar;
-                        wr = w * r;
-                    }
-                } else {
-                    acc[0] = fmaf(r, r, acc[0]);
-                }
-                acc[1] += 1.0f;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q], wr, acc[2 + q]);
-                int h = 8;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const float jq = (c.huber > 0.f) ? w * J[q] : J[q];
-#pragma unroll
-                    for (int s = q; s < 6; ++s) {
-                        acc[h] = fmaf(jq, J[s], acc[h]);
-                        ++h;
-                    }
-                }
-            }
-        }
-        if (WRITE_RES) residuals[i] = res;
-    }
-}
-
-// Workgroup reduction of the 29 partial sums: xor-butterfly inside each wavefront, then a fixed-order sum over the
-// wavefronts through LDS. Every thread returns with the totals in acc[]. Deterministic for a given BLOCK.
-template <int BLOCK>
-__device__ __forceinline__ void block_reduce(float acc[NACC], float* s_part /* [BLOCK/64][32] */, float* s_tot /* [32] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        float v = acc[i];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        acc[i] = v;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) s_part[wave * 32 + i] = acc[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) t += s_part[w * 32 + threadIdx.x];
-        s_tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = s_tot[i];
-}
-
-struct EvalOut {  // EvalData of lm_optimizer.rs:31-40 (model kept separately)
-    float energy;
-    float g[6];
-    float h[36];
-};
-__device__ __forceinline__ void unpack_eval(const float acc[NACC], EvalOut* e) {
-    e->energy = acc[0] / acc[1];  // energy_sum / residuals.len()  (0/0 = NaN as in the reference)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) e->g[q] = acc[2 + q];
-    int h = 8;
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int s = q; s < 6; ++s) {
-            e->h[q * 6 + s] = acc[h];
-            e->h[s * 6 + q] = acc[h];
-            ++h;
-        }
-}
-
-// optimizer::State::iterative_solve (optimizer.rs:57-70) with LMOptimizerState's init / step / eval / stop_criterion
-// (lm_optimizer.rs:113-192), executed redundantly by every thread on workgroup-uniform values.
-// Returns false when step() fails (Cholesky); *model is then left untouched (the level's progress is discarded like
-// the reference's `Err(err) => break`, inverse_compositional.rs:195-199).
-template <int BLOCK>
-__device__ bool solve_level(const EvalCtx& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out, float* s_part,
-                            float* s_tot) {
-    float acc[NACC];
-    EvalOut cur;
-    Iso cur_model = *model;
-    eval_accumulate<BLOCK, false>(c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
-    block_reduce<BLOCK>(acc, s_part, s_tot);
-    unpack_eval(acc, &cur);
-    float lm_coef = 0.1f;
-    int nb_iter = 0;
-    for (;;) {
-        nb_iter += 1;
-        Iso cand;
-        if (!lm_step(cur.h, cur.g, cur_model, lm_coef, &cand)) return false;  // step(): lm_optimizer.rs:123-136
-        eval_accumulate<BLOCK, false>(c, cand, acc, nullptr);                  // eval(): lm_optimizer.rs:140-149
-        block_reduce<BLOCK>(acc, s_part, s_tot);
-        const float energy = acc[0] / acc[1];
-        const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
-        if (energy > cur.energy) {                      // Err(energy)
-            if (too_many_iterations) break;
-            lm_coef *= 10.0f;
-            continue;
-        }
-        const float d_energy = cur.energy - energy;
-        unpack_eval(acc, &cur);
-        cur_model = cand;
-        if (too_many_iterations) break;
-        lm_coef = 0.1f * lm_coef;
-        if (!(d_energy > 1.0f)) break;
-    }
-    *model = cur_model;
-    *nb_iter_out = nb_iter;
-    *energy_out = cur.energy;
-    *lm_coef_out = lm_coef;
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
-// ------------------------------------------------------------------------------------------------------------
-#define LM_BLOCK 256
-__global__ __launch_bounds__(LM_BLOCK) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0,
-                                                             const uint8_t* __restrict__ curu, Records rec,
-                                                             const float* __restrict__ prev_poses7,
-                                                             const float* __restrict__ kf_poses7, float* __restrict__ out_poses7,
-                                                             int32_t* __restrict__ out_status,
-                                                             vors_pair_stats* __restrict__ out_stats) {
-    __shared__ float s_part[(LM_BLOCK / 64) * 32];
-    __shared__ float s_tot[32];
-    const int pair = blockIdx.x;
-    const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
-    const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
-    Iso lm_model = iso_mul(iso_inverse(prev_pose), kf_pose);  // inverse_compositional.rs:177
-    bool went_well = true;
-    const size_t rbase = (size_t)pair * g.slots_total;
-    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
-        EvalCtx c;
-        c.img = level_ptr(g, cur0, curu, pair, lvl);
-        c.rows = g.lv[lvl].rows;
-        c.cols = g.lv[lvl].cols;
-        c.k = g.lv[lvl].k;
-        c.A = rec.A + rbase + g.lv[lvl].slot_off;
-        c.B = rec.B + rbase + g.lv[lvl].slot_off;
-        c.C = rec.C + rbase + g.lv[lvl].slot_off;
-        c.n_slots = g.lv[lvl].n_slots;
-        c.huber = g.huber_delta;
-        int nb_iter = 0;
-        float energy = 0.f, lm_coef = 0.f;
-        const bool ok = solve_level<LM_BLOCK>(c, &lm_model, &nb_iter, &energy, &lm_coef, s_part, s_tot);
-        if (out_stats && threadIdx.x == 0) {
-            out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
-            out_stats[pair].energy[lvl] = ok ? energy : 0.f;
-        }
-        if (!ok) {
-            went_well = false;
-            if (out_stats && threadIdx.x == 0)
-                for (int l2 = lvl - 1; l2 >= 0; --l2) {
-                    out_stats[pair].nb_iter[l2] = 0;
-                    out_stats[pair].energy[l2] = 0.f;
-                }
-            break;
-        }
-    }
-    // keyframe test on the coarsest level (inverse_compositional.rs:211-224)
-    float flow_sum = 0.f, flow_n = 0.f;
-    {
-        const int lvl = g.L - 1;
-        const float4* A = rec.A + rbase + g.lv[lvl].slot_off;
-        const uint32_t* XY = rec.XY + rbase + g.lv[lvl].slot_off;
-        for (int i = threadIdx.x; i < g.lv[lvl].n_slots; i += LM_BLOCK) {
-            const float4 a = A[i];
-            if (a.w >= 0.f) {
-                const uint32_t p = XY[i];
-                const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
-                float u, v;
-                project_uv(g.lv[lvl].k, iso_transform_point(lm_model, V3{a.x, a.y, a.z}), &u, &v);
-                flow_sum += fabsf(x - u) + fabsf(y - v);
-                flow_n += 1.0f;
-            }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            flow_sum += __shfl_xor(flow_sum, m);
-            flow_n += __shfl_xor(flow_n, m);
-        }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) {
-            s_part[(threadIdx.x >> 6) * 2] = flow_sum;
-            s_part[(threadIdx.x >> 6) * 2 + 1] = flow_n;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float fs = 0.f, fn = 0.f;
-        for (int w = 0; w < LM_BLOCK / 64; ++w) {
-            fs += s_part[2 * w];
-            fn += s_part[2 * w + 1];
-        }
-        const float optical_flow = fs / fn;
-        const Iso pose = went_well ? iso_mul(kf_pose, iso_inverse(lm_model)) : prev_pose;  // inverse_compositional.rs:206-208
-        iso_store(pose, out_poses7 + 7 * pair);
-        out_status[pair] = went_well ? VORS_TRACK_OK : VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT;
-        if (out_stats) {
-            iso_store(lm_model, out_stats[pair].lm_model);
-            out_stats[pair].optical_flow = optical_flow;
-            out_stats[pair].change_keyframe = (optical_flow >= 1.0f) ? 1 : 0;
-        }
-    }
-    // usable candidates per level (diagnostics)
-    if (out_stats) {
-        for (int lvl = 0; lvl < g.L; ++lvl) {
-            const float4* A = rec.A + rbase + g.lv[lvl].slot_off;
-            int n = 0;
-            for (int i = threadIdx.x; i < g.lv[lvl].n_slots; i += LM_BLOCK) n += (A[i].w >= 0.f) ? 1 : 0;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (float)n;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                float t = 0.f;
-                for (int w = 0; w < LM_BLOCK / 64; ++w) t += s_part[w];
-                out_stats[pair].n_points[lvl] = (int)t;
-            }
-        }
-        if (threadIdx.x == 0)
-            for (int lvl = g.L; lvl < VORS_MAX_LEVELS; ++lvl) {
-                out_stats[pair].nb_iter[lvl] = 0;
-                out_stats[pair].n_points[lvl] = 0;
-                out_stats[pair].energy[lvl] = 0.f;
-            }
-    }
-}
-
-void launch_lm_track(const Geom& g, Pyramid cur, Records rec, const float* prev_poses7, const float* kf_poses7,
-                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(lm_track_kernel, dim3(n_pairs), dim3(LM_BLOCK), 0, s, g, cur.level0, cur.upper, rec, prev_poses7, kf_poses7,
-                       out_poses7, out_status, out_stats);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Operator level (one pyramid level, explicit observations)
-// ------------------------------------------------------------------------------------------------------------
-__global__ void records_from_obs_kernel(Intr k, int rows, int cols, const uint8_t* __restrict__ tmpl, int n,
-                                        const int32_t* __restrict__ xy, const float* __restrict__ iz,
-                                        const float* __restrict__ jac, Records rec) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = xy[2 * i], y = xy[2 * i + 1];
-    const V3 P = back_project(k, (float)x, (float)y, 1.0f / iz[i]);
-    rec.A[i] = make_float4(P.x, P.y, P.z, (float)tmpl[(size_t)y * cols + x]);
-    rec.B[i] = make_float4(jac[6 * i], jac[6 * i + 1], jac[6 * i + 2], jac[6 * i + 3]);
-    rec.C[i] = make_float2(jac[6 * i + 4], jac[6 * i + 5]);
-    rec.XY[i] = (uint32_t)x | ((uint32_t)y << 16);
-    rec.IZ[i] = iz[i];
-}
-void launch_records_from_obs(Intr k, int rows, int cols, const uint8_t* tmpl, int n, const int32_t* xy, const float* iz,
-                             const float* jac, Records rec, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(records_from_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, k, rows, cols, tmpl, n, xy, iz, jac, rec);
-}
-
-__global__ __launch_bounds__(LM_BLOCK) void lm_eval_obs_kernel(EvalCtx c, const float* __restrict__ model7, float* __restrict__ out,
-                                                                float* __restrict__ residuals) {
-    __shared__ float s_part[(LM_BLOCK / 64) * 32];
-    __shared__ float s_tot[32];
-    float acc[NACC];
-    const Iso model = iso_load(model7);
-    if (residuals)
-        eval_accumulate<LM_BLOCK, true>(c, model, acc, residuals);
-    else
-        eval_accumulate<LM_BLOCK, false>(c, model, acc, nullptr);
-    block_reduce<LM_BLOCK>(acc, s_part, s_tot);
-    if (threadIdx.x == 0) {
-        EvalOut e;
-        unpack_eval(acc, &e);
-        out[0] = e.energy;
-        out[1] = acc[1];
-        for (int q = 0; q < 6; ++q) out[2 + q] = e.g[q];
-        for (int q = 0; q < 36; ++q) out[8 + q] = e.h[q];
-    }
-}
-static EvalCtx make_ctx(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber) {
-    EvalCtx c;
-    c.img = image;
-    c.rows = rows;
-    c.cols = cols;
-    c.k = k;
-    c.A = rec.A;
-    c.B = rec.B;
-    c.C = rec.C;
-    c.n_slots = n;
-    c.huber = huber;
-    return c;
-}
-void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
-                        const float* model7, float* out, float* residuals, hipStream_t s) {
-    hipLaunchKernelGGL(lm_eval_obs_kernel, dim3(1), dim3(LM_BLOCK), 0, s, make_ctx(k, rows, cols, image, n, rec, huber_delta), model7,
-                       out, residuals);
-}
-
-__global__ __launch_bounds__(LM_BLOCK) void lm_solve_obs_kernel(EvalCtx c, const float* __restrict__ model7, float* __restrict__ out) {
-    __shared__ float s_part[(LM_BLOCK / 64) * 32];
-    __shared__ float s_tot[32];
-    Iso model = iso_load(model7);
-    int nb_iter = 0;
-    float energy = 0.f, lm_coef = 0.f;
-    const bool ok = solve_level<LM_BLOCK>(c, &model, &nb_iter, &energy, &lm_coef, s_part, s_tot);
-    if (threadIdx.x == 0) {
-        iso_store(model, out);
-        out[7] = (float)nb_iter;
-        out[8] = energy;
-        out[9] = lm_coef;
-        out[10] = ok ? 0.f : 1.f;
-    }
-}
-void launch_lm_solve_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
-                         const float* model7, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(lm_solve_obs_kernel, dim3(1), dim3(LM_BLOCK), 0, s, make_ctx(k, rows, cols, image, n, rec, huber_delta), model7,
-                       out);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,809 @@
+// The Levenberg-Marquardt kernels of the direct-alignment hot path (gfx950 / CDNA4, wave64).
+//
+//   lm_track_kernel<BLOCK, Src>   Tracker::track's coarse->fine loop (reference src/core/track/inverse_compositional.rs:177-224)
+//                                 with the whole optimizer::State loop (src/math/optimizer.rs:57-70,
+//                                 src/core/track/lm_optimizer.rs:68-193) on the device: ONE workgroup per frame pair for all
+//                                 levels and iterations; optimizer state lives in LDS; no host round trip.
+//   lm_eval_obs_kernel            eval_energy + compute_eval_data for explicit observations (operator level)
+//   lm_solve_obs_kernel           iterative_solve for explicit observations (operator level)
+//
+// Evaluation = eval_energy + compute_eval_data fused in ONE pass (lm_optimizer.rs:68-107): per point rotate+translate,
+// project, strict inside test, 4 u8 taps, bilinear, residual, then 29 partial sums (sum r^2, count, g = sum J r (6),
+// H = sum J J^T (21 unique)). J J^T is recomputed from J instead of streaming the reference's precomputed 6x6.
+// Reduction: per-lane strided partial sums -> DPP row/bank reductions inside the wavefront -> fixed-order sum over the
+// wavefronts through LDS. Deterministic for a given BLOCK. No MFMA: this is a reduction, not a contraction.
+//
+// Compile with -ffp-contract=off: per-point arithmetic follows the reference's evaluation order exactly (per-point
+// residuals are bit-identical to the oracle); explicit fmaf only where the summation order differs anyway.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "device_common.h"
+#include "engine.h"
+
+namespace vors {
+
+#define NACC 29
+#define LM_MAX_WAVES 16
+
+struct LmShared {
+    float part[LM_MAX_WAVES * 32];  // per-wavefront partial sums
+    float sums[2][32];              // ping-pong totals: [cur] = kept state's sums, [1-cur] = candidate's
+    float cand[8];                  // candidate model (7) + step-ok flag, broadcast from the solving lane
+    float misc[LM_MAX_WAVES * 2];
+};
+
+// A candidate point ready for warping: back-projected keyframe point + template grey level (< 0 = empty slot).
+struct Pos {
+    float X, Y, Z;  // camera.rs:135-140 applied to (x, y, 1/_z)
+    float tmpl;
+};
+
+// Point sources hand out GROUPS of G independent points per thread and iteration (instruction-level parallelism):
+//   fetch(cursor, n_units, raw)   issue every load of the group
+//   positions(raw, pos[G])        back-projected points (cheap part, needed before the taps can be addressed)
+//   jacobians(raw, J[G][6])       warp Jacobians (inverse_compositional.rs:313-341) — evaluated while the taps are in flight
+//   slot(raw, g)                  record index of point g (only used when residuals are written, operator level)
+
+// ---- point source: stored record planes (sparse mode, operator level). G = 2 slots (i, i + BLOCK).
+struct RecSrc {
+    static constexpr int G = 2;
+    const float4* A;
+    const float4* B;
+    const float2* C;
+    struct Raw {
+        float4 a[2], b[2];
+        float2 c[2];
+        int i[2];
+    };
+    struct Cursor {
+        int i;
+    };
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor begin() const {
+        return Cursor{(int)threadIdx.x};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor advance(const Cursor& c) const {
+        return Cursor{c.i + 2 * BLOCK};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const Cursor& cur, int n, Raw& r) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int i = cur.i + g * BLOCK;
+            r.i[g] = i;
+            r.a[g] = (i < n) ? A[i] : make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const bool v = r.a[g].w >= 0.f;
+            r.b[g] = v ? B[r.i[g]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.c[g] = v ? C[r.i[g]] : make_float2(0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void positions(const Raw& r, Pos p[2]) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) p[g] = Pos{r.a[g].x, r.a[g].y, r.a[g].z, r.a[g].w};
+    }
+    __device__ __forceinline__ void jacobians(const Raw& r, float J[2][6]) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            J[g][0] = r.b[g].x; J[g][1] = r.b[g].y; J[g][2] = r.b[g].z; J[g][3] = r.b[g].w;
+            J[g][4] = r.c[g].x; J[g][5] = r.c[g].y;
+        }
+    }
+    __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.i[g] < n ? r.i[g] : -1; }
+};
+
+// ---- point sources for dense mode: NOTHING is stored per point at level 0. Each evaluation recomputes the point from the
+// keyframe image (template + integer gradient, gradient.rs:15-33 / 74-93), the depth map (level 0: from_depth,
+// inverse_depth.rs:24-29) or the fused inverse-depth plane (levels >= 1), with exactly the arithmetic of the keyframe
+// precompute (back_project camera.rs:135-140, warp_jacobian_at inverse_compositional.rs:313-341): bit-identical points
+// for ~4 B of HBM traffic per point instead of 40.
+//
+// DenseSrc: one pixel per unit, any image width (fallback, keyframe test, diagnostics).
+template <bool LEVEL0>
+struct DenseSrc {
+    static constexpr int G = 1;
+    const uint8_t* kimg;    // keyframe image of this level
+    const uint8_t* kfine;   // next finer keyframe level (levels >= 1)
+    const uint16_t* depth;  // level 0
+    const float* iz;        // levels >= 1: fused inverse depth, NaN = Unknown
+    int rows, cols, fcols;
+    Intr k;
+    float depth_scale;
+    struct Cursor {
+        int i, x, y;
+    };
+    struct Raw {
+        int i, x, y;
+        float izv;
+        int gx, gy, tm;
+        bool valid;
+    };
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor begin() const {
+        const int t = (int)threadIdx.x;
+        const int y = t / cols;
+        return Cursor{t, t - y * cols, y};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor advance(const Cursor& c) const {
+        const int dy = BLOCK / cols, dx = BLOCK - dy * cols;  // workgroup-uniform
+        int x = c.x + dx, y = c.y + dy;
+        if (x >= cols) {
+            x -= cols;
+            y += 1;
+        }
+        return Cursor{c.i + BLOCK, x, y};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const Cursor& c, int n, Raw& r) const {
+        r.i = c.i;
+        r.x = c.x;
+        r.y = c.y;
+        r.tm = kimg[c.i];
+        if (LEVEL0) {
+            const bool interior = c.x > 0 && c.y > 0 && c.x < cols - 1 && c.y < rows - 1;
+            const uint8_t* p = kimg + c.i;
+            const int l = p[interior ? -1 : 0], rr = p[interior ? 1 : 0], u = p[interior ? -cols : 0], d = p[interior ? cols : 0];
+            r.gx = (rr - l) / 2;  // borders: the taps alias the centre pixel -> 0, like gradient.rs:15-33
+            r.gy = (d - u) / 2;
+            const int dz = depth[c.i];
+            r.valid = dz != 0;
+            r.izv = depth_scale / (float)dz;
+        } else {
+            const uint8_t* p = kfine + (size_t)(2 * c.y) * fcols + 2 * c.x;
+            const int a = p[0], cc = p[1], b = p[fcols], d = p[fcols + 1];
+            r.gx = (cc + d - a - b) / 2;
+            r.gy = (b - a + d - cc) / 2;
+            r.izv = iz[c.i];
+            r.valid = !(r.izv != r.izv);
+        }
+    }
+    __device__ __forceinline__ void positions(const Raw& r, Pos p[1]) const {
+        const V3 P = back_project(k, (float)r.x, (float)r.y, 1.0f / r.izv);
+        p[0] = Pos{P.x, P.y, P.z, r.valid ? (float)r.tm : -1.0f};
+    }
+    __device__ __forceinline__ void jacobians(const Raw& r, float J[1][6]) const {
+        warp_jacobian_at((float)r.gx, (float)r.gy, (float)r.x, (float)r.y, r.izv, k, J[0]);
+    }
+    __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.i; }
+};
+
+// DenseQuadSrc: FOUR horizontally adjacent pixels per unit (cols % 4 == 0). One dword / dwordx2 / dwordx4 load per image
+// row and plane instead of ~8 byte loads per pixel: coalesced 256 B - 1 KiB per wavefront instruction, 4-way ILP per lane.
+template <bool LEVEL0>
+struct DenseQuadSrc {
+    static constexpr int G = 4;
+    const uint8_t* kimg;
+    const uint8_t* kfine;
+    const uint16_t* depth;
+    const float* iz;
+    int rows, cols, fcols, qcols;  // qcols = cols / 4
+    Intr k;
+    float depth_scale;
+    struct Cursor {
+        int i, qx, y;  // i = quad index
+    };
+    struct Raw {
+        int x0, y;
+        float izv[4];
+        int gx[4], gy[4], tm[4];
+        bool valid[4];
+    };
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor begin() const {
+        const int t = (int)threadIdx.x;
+        const int y = t / qcols;
+        return Cursor{t, t - y * qcols, y};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor advance(const Cursor& c) const {
+        const int dy = BLOCK / qcols, dx = BLOCK - dy * qcols;  // workgroup-uniform
+        int qx = c.qx + dx, y = c.y + dy;
+        if (qx >= qcols) {
+            qx -= qcols;
+            y += 1;
+        }
+        return Cursor{c.i + BLOCK, qx, y};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const Cursor& c, int n, Raw& r) const {
+        const int x0 = 4 * c.qx, y = c.y;
+        r.x0 = x0;
+        r.y = y;
+        const uint8_t* row = kimg + (size_t)y * cols + x0;
+        const uint32_t cw = *reinterpret_cast<const uint32_t*>(row);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.tm[j] = (cw >> (8 * j)) & 0xff;
+        if (LEVEL0) {
+            // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33)
+            const bool yin = y > 0 && y < rows - 1;
+            const uint32_t uw = *reinterpret_cast<const uint32_t*>(row - (yin ? cols : 0));
+            const uint32_t dw = *reinterpret_cast<const uint32_t*>(row + (yin ? cols : 0));
+            const int lft = row[x0 > 0 ? -1 : 0];
+            const int rgt = row[x0 + 4 < cols ? 4 : 3];
+            const uint2 dzw = *reinterpret_cast<const uint2*>(depth + (size_t)y * cols + x0);
+            const int b[6] = {lft, r.tm[0], r.tm[1], r.tm[2], r.tm[3], rgt};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                const bool xin = x > 0 && x < cols - 1;
+                const int up = (uw >> (8 * j)) & 0xff, dn = (dw >> (8 * j)) & 0xff;
+                r.gx[j] = (xin && yin) ? (b[j + 2] - b[j]) / 2 : 0;
+                r.gy[j] = (xin && yin) ? (dn - up) / 2 : 0;
+                const int dz = (j < 2 ? (dzw.x >> (16 * j)) : (dzw.y >> (16 * (j - 2)))) & 0xffff;
+                r.valid[j] = dz != 0;
+                r.izv[j] = depth_scale / (float)dz;
+            }
+        } else {
+            // 2x2 block gradients of the next finer level (gradient.rs:74-93): pixels (2y, 2x0 .. 2x0+7) and the row below
+            const uint8_t* f = kfine + (size_t)(2 * y) * fcols + 2 * x0;
+            const uint2 f0 = *reinterpret_cast<const uint2*>(f);
+            const uint2 f1 = *reinterpret_cast<const uint2*>(f + fcols);
+            const float4 z4 = *reinterpret_cast<const float4*>(iz + (size_t)y * cols + x0);
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w0 = j < 2 ? f0.x : f0.y, w1 = j < 2 ? f1.x : f1.y;
+                const int sh = (j & 1) * 16;
+                const int a = (w0 >> sh) & 0xff, cc = (w0 >> (sh + 8)) & 0xff;
+                const int bb = (w1 >> sh) & 0xff, d = (w1 >> (sh + 8)) & 0xff;
+                r.gx[j] = (cc + d - a - bb) / 2;
+                r.gy[j] = (bb - a + d - cc) / 2;
+                r.izv[j] = zz[j];
+                r.valid[j] = !(zz[j] != zz[j]);
+            }
+        }
+    }
+    __device__ __forceinline__ void positions(const Raw& r, Pos p[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const V3 P = back_project(k, (float)(r.x0 + j), (float)r.y, 1.0f / r.izv[j]);
+            p[j] = Pos{P.x, P.y, P.z, r.valid[j] ? (float)r.tm[j] : -1.0f};
+        }
+    }
+    __device__ __forceinline__ void jacobians(const Raw& r, float J[4][6]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            warp_jacobian_at((float)r.gx[j], (float)r.gy[j], (float)(r.x0 + j), (float)r.y, r.izv[j], k, J[j]);
+    }
+    __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.y * cols + r.x0 + g; }
+};
+
+struct ImgCtx {
+    const uint8_t* img;  // current image of this level, row-major
+    int rows, cols;
+    Intr k;
+    float huber;
+};
+
+// warp (lm_optimizer.rs:213-219) + interpolate's inside test (lm_optimizer.rs:227-231): tap address or "outside".
+struct Warped {
+    float u, v, uf, vf;
+    int off;      // offset of tap (v0, u0); 0 when outside (a safe address)
+    bool inside;  // valid && inside
+};
+__device__ __forceinline__ Warped warp_point(const ImgCtx& c, const Iso& model, const Pos& p) {
+    Warped w;
+    const V3 p2 = iso_transform_point(model, V3{p.X, p.Y, p.Z});
+    project_uv(c.k, p2, &w.u, &w.v);
+    w.uf = floorf(w.u);
+    w.vf = floorf(w.v);
+    w.inside = (p.tmpl >= 0.f) && (w.uf >= 0.f) && (w.uf < (float)(c.cols - 2)) && (w.vf >= 0.f) && (w.vf < (float)(c.rows - 2));
+    w.off = w.inside ? (int)w.vf * c.cols + (int)w.uf : 0;
+    return w;
+}
+struct Taps {
+    uint32_t top, bot;  // (t00 | t01 << 8), (t10 | t11 << 8)
+};
+__device__ __forceinline__ Taps load_taps(const ImgCtx& c, const Warped& w) {
+    const uint8_t* q = c.img + w.off;
+    uint16_t a, b;
+    __builtin_memcpy(&a, q, 2);  // two adjacent bytes per row: one (possibly unaligned) 16-bit load each
+    __builtin_memcpy(&b, q + c.cols, 2);
+    return Taps{a, b};
+}
+// bilinear (lm_optimizer.rs:236-247, term order as written) + residual + the 29 sums. Returns the residual (NaN if outside).
+template <bool HUBER>
+__device__ __forceinline__ float accumulate_point(const ImgCtx& c, float tmpl, const float J[6], const Warped& w, const Taps& t,
+                                                  float acc[NACC]) {
+    const float vu_00 = (float)(t.top & 0xff), vu_01 = (float)(t.top >> 8), vu_10 = (float)(t.bot & 0xff), vu_11 = (float)(t.bot >> 8);
+    const float fa = w.u - w.uf, fb = w.v - w.vf;
+    const float im = (1.0f - fb) * (1.0f - fa) * vu_00 + fb * (1.0f - fa) * vu_10 + (1.0f - fb) * fa * vu_01 + fb * fa * vu_11;
+    const float r_true = im - tmpl;
+    // Outside / empty points contribute exactly nothing: selected to zero (never multiplied: 0 * inf would poison the sums).
+    const float r = w.inside ? r_true : 0.f;
+    float Jm[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Jm[q] = w.inside ? J[q] : 0.f;
+    float wgt = 1.0f, wr = r;
+    if (HUBER) {  // extension (not in the reference)
+        const float ar = fabsf(r);
+        const bool lin = ar > c.huber;
+        acc[0] += lin ? c.huber * (2.0f * ar - c.huber) : r * r;
+        wgt = lin ? c.huber / ar : 1.0f;
+        wr = wgt * r;
+    } else {
+        acc[0] = fmaf(r, r, acc[0]);
+    }
+    acc[1] += w.inside ? 1.0f : 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(Jm[q], wr, acc[2 + q]);
+    int h = 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float jq = HUBER ? wgt * Jm[q] : Jm[q];
+#pragma unroll
+        for (int s = q; s < 6; ++s) {
+            acc[h] = fmaf(jq, Jm[s], acc[h]);
+            ++h;
+        }
+    }
+    return w.inside ? r_true : __builtin_nanf("");
+}
+
+// Values read from LDS are uniform across the workgroup but land in vector registers; readfirstlane moves them to SGPRs.
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ Iso iso_uniform(const Iso& m) {
+    return Iso{V3{uniform_f(m.t.x), uniform_f(m.t.y), uniform_f(m.t.z)}, Quat{uniform_f(m.q.i), uniform_f(m.q.j), uniform_f(m.q.k), uniform_f(m.q.w)}};
+}
+
+// One evaluation sweep over the units of a level: each thread accumulates its strided share, Src::G points in flight.
+template <int BLOCK, bool HUBER, bool WRITE_RES, class Src>
+__device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, const ImgCtx& c, const Iso& model, float acc[NACC],
+                                                float* residuals) {
+    constexpr int G = Src::G;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    for (typename Src::Cursor cur = src.template begin<BLOCK>(); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
+        typename Src::Raw raw;
+        src.template fetch<BLOCK>(cur, n_units, raw);
+        Pos pos[G];
+        src.positions(raw, pos);
+        Warped w[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) w[g] = warp_point(c, model, pos[g]);
+        Taps t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) t[g] = load_taps(c, w[g]);
+        float J[G][6];
+        src.jacobians(raw, J);  // independent of the taps: overlaps their latency
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float res = accumulate_point<HUBER>(c, pos[g].tmpl, J[g], w[g], t[g], acc);
+            if (WRITE_RES) {
+                const int sl = src.slot(raw, g, n_units);
+                if (sl >= 0) residuals[sl] = res;
+            }
+        }
+    }
+}
+
+// ---- wavefront reduction with DPP (no LDS traffic): after the 6 steps lane 63 holds the sum of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror  -> every lane of a row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    return v;
+}
+
+// Workgroup reduction of the 29 partial sums into s.sums[dst][0..28]. Ends with a barrier.
+template <int BLOCK>
+__device__ __forceinline__ void block_reduce(const float acc[NACC], LmShared& s, int dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(acc[i])), 63));
+        mine = (lane == i) ? tot : mine;
+    }
+    if (lane < NACC) s.part[wave * 32 + lane] = mine;
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) t += s.part[w * 32 + threadIdx.x];
+        s.sums[dst][threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// step(): lm_optimizer.rs:123-136, by ONE lane on the kept state's sums; result broadcast through LDS.
+__device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso& model, float lm_coef) {
+    if (threadIdx.x == 0) {
+        const float* a = s.sums[cur];
+        float h[36], g[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) g[q] = a[2 + q];
+        int k = 8;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int r = q; r < 6; ++r) {
+                h[q * 6 + r] = a[k];
+                h[r * 6 + q] = a[k];
+                ++k;
+            }
+        Iso cand;
+        const bool ok = lm_step(h, g, model, lm_coef, &cand);
+        iso_store(cand, s.cand);
+        s.cand[7] = ok ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+}
+
+// optimizer::State::iterative_solve (optimizer.rs:57-70) with LMOptimizerState's init / step / eval / stop_criterion
+// (lm_optimizer.rs:113-192). All control values are workgroup-uniform (read from LDS). Returns false when step() fails
+// (Cholesky); *model is then left untouched: the level's progress is discarded like the reference's `Err(err) => break`
+// (inverse_compositional.rs:195-199).
+template <int BLOCK, bool HUBER, class Src>
+__device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* model, int* nb_iter_out, float* energy_out,
+                            float* lm_coef_out, LmShared& s) {
+    float acc[NACC];
+    Iso cur_model = *model;
+    int cur = 0;
+    eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
+    block_reduce<BLOCK>(acc, s, cur);
+    float cur_energy = uniform_f(s.sums[cur][0] / s.sums[cur][1]);  // energy_sum / residuals.len(): 0/0 = NaN like the reference
+    float lm_coef = 0.1f;
+    int nb_iter = 0;
+    for (;;) {
+        nb_iter += 1;
+        solve_step_lane0(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
+        if (uniform_f(s.cand[7]) == 0.0f) return false;
+        const Iso cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
+        eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cand, acc, nullptr);  // eval(): lm_optimizer.rs:140-149
+        block_reduce<BLOCK>(acc, s, 1 - cur);
+        const float energy = uniform_f(s.sums[1 - cur][0] / s.sums[1 - cur][1]);
+        const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
+        if (energy > cur_energy) {                      // Err(energy)
+            if (too_many_iterations) break;
+            lm_coef *= 10.0f;
+            continue;
+        }
+        const float d_energy = cur_energy - energy;
+        cur = 1 - cur;  // the candidate's sums become the kept state (no copy)
+        cur_energy = energy;
+        cur_model = cand;
+        if (too_many_iterations) break;
+        lm_coef = 0.1f * lm_coef;
+        if (!(d_energy > 1.0f)) break;
+    }
+    *model = cur_model;
+    *nb_iter_out = nb_iter;
+    *energy_out = cur_energy;
+    *lm_coef_out = lm_coef;
+    return true;
+}
+
+// Sum of two per-thread values over the workgroup (keyframe test, point counts). Ends with a barrier; result uniform.
+template <int BLOCK>
+__device__ __forceinline__ void block_sum2(float& a, float& b, LmShared& s) {
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(a)), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(b)), 63));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        s.misc[(threadIdx.x >> 6) * 2] = a;
+        s.misc[(threadIdx.x >> 6) * 2 + 1] = b;
+    }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        ta += s.misc[2 * w];
+        tb += s.misc[2 * w + 1];
+    }
+    a = ta;
+    b = tb;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
+// ------------------------------------------------------------------------------------------------------------
+// Per-level dispatch: build the point source of a level and run `f(src, n_slots)`.
+template <bool DENSE, bool QUADS, class F>
+__device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pair, const uint8_t* kf0, const uint8_t* kfu,
+                                                  const uint16_t* kf_depth, const Records& rec, F&& f) {
+    const LevelGeom lg = g.lv[lvl];
+    if constexpr (DENSE) {
+        const uint8_t* kimg = level_ptr(g, kf0, kfu, pair, lvl);
+        const uint8_t* kfine = lvl > 0 ? level_ptr(g, kf0, kfu, pair, lvl - 1) : nullptr;
+        const uint16_t* depth = kf_depth + (size_t)pair * g.S0;
+        const float* iz = lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr;
+        const int fcols = lvl > 0 ? g.lv[lvl - 1].cols : 0;
+        // quads need 4-byte aligned rows in every plane they read (and 16-byte aligned inverse-depth rows)
+        const bool quad_ok = QUADS && (lg.cols % 4 == 0) && (lvl == 0 ? (g.S0 % 4 == 0) : (fcols % 8 == 0));
+        if (lvl == 0) {
+            if constexpr (QUADS) {
+                if (quad_ok) {
+                    DenseQuadSrc<true> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, lg.k, g.depth_scale};
+                    f(src, lg.rows * (lg.cols / 4));
+                    return;
+                }
+            }
+            DenseSrc<true> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.k, g.depth_scale};
+            f(src, lg.n_slots);
+        } else {
+            if constexpr (QUADS) {
+                if (quad_ok) {
+                    DenseQuadSrc<false> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, lg.k, g.depth_scale};
+                    f(src, lg.rows * (lg.cols / 4));
+                    return;
+                }
+            }
+            DenseSrc<false> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.k, g.depth_scale};
+            f(src, lg.n_slots);
+        }
+    } else {
+        const size_t rb = (size_t)pair * g.slots_total + lg.slot_off;
+        RecSrc src{rec.A + rb, rec.B + rb, rec.C + rb};
+        f(src, lg.n_slots);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
+// ------------------------------------------------------------------------------------------------------------
+template <int BLOCK, bool HUBER, bool DENSE>
+__global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                          const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                          const uint16_t* __restrict__ kf_depth, Records rec,
+                                                          const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
+                                                          float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
+                                                          vors_pair_stats* __restrict__ out_stats) {
+    __shared__ LmShared s;
+    const int pair = blockIdx.x;
+    const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
+    const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
+    Iso lm_model = iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
+    bool went_well = true;
+    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
+        ImgCtx c;
+        c.img = level_ptr(g, cur0, curu, pair, lvl);
+        c.rows = g.lv[lvl].rows;
+        c.cols = g.lv[lvl].cols;
+        c.k = g.lv[lvl].k;
+        c.huber = g.huber_delta;
+        int nb_iter = 0;
+        float energy = 0.f, lm_coef = 0.f;
+        bool ok = false;
+#ifdef VORS_PROFILE_LEVELS
+        const long long t_level0 = wall_clock64();
+#endif
+        with_level_source<DENSE, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
+            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s);
+        });
+        if (out_stats && threadIdx.x == 0) {
+            out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
+            out_stats[pair].energy[lvl] = ok ? energy : 0.f;
+#ifdef VORS_PROFILE_LEVELS
+            out_stats[pair].energy[lvl] = (float)(wall_clock64() - t_level0) * 0.01f;  // 100 MHz ticks -> microseconds
+#endif
+        }
+        if (!ok) {
+            went_well = false;
+            if (out_stats && threadIdx.x == 0)
+                for (int l2 = lvl - 1; l2 >= 0; --l2) {
+                    out_stats[pair].nb_iter[l2] = 0;
+                    out_stats[pair].energy[l2] = 0.f;
+                }
+            break;
+        }
+    }
+    // keyframe test on the coarsest level (inverse_compositional.rs:211-224), with the last lm_model even after a failure
+    float flow_sum = 0.f, flow_n = 0.f;
+    {
+        const int lvl = g.L - 1;
+        const Intr k = g.lv[lvl].k;
+        if constexpr (DENSE) {
+            with_level_source<true, false>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
+                for (auto cu = src.template begin<BLOCK>(); cu.i < n_slots; cu = src.template advance<BLOCK>(cu)) {
+                    typename std::remove_reference<decltype(src)>::type::Raw r;
+                    src.template fetch<BLOCK>(cu, n_slots, r);
+                    Pos p[1];
+                    src.positions(r, p);
+                    if (p[0].tmpl >= 0.f) {
+                        float u, v;
+                        project_uv(k, iso_transform_point(lm_model, V3{p[0].X, p[0].Y, p[0].Z}), &u, &v);
+                        flow_sum += fabsf((float)cu.x - u) + fabsf((float)cu.y - v);
+                        flow_n += 1.0f;
+                    }
+                }
+            });
+        } else {
+            const size_t rb = (size_t)pair * g.slots_total + g.lv[lvl].slot_off;
+            const float4* A = rec.A + rb;
+            const uint32_t* XY = rec.XY + rb;
+            for (int i = threadIdx.x; i < g.lv[lvl].n_slots; i += BLOCK) {
+                const float4 a = A[i];
+                if (a.w >= 0.f) {
+                    const uint32_t p = XY[i];
+                    const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
+                    float u, v;
+                    project_uv(k, iso_transform_point(lm_model, V3{a.x, a.y, a.z}), &u, &v);
+                    flow_sum += fabsf(x - u) + fabsf(y - v);
+                    flow_n += 1.0f;
+                }
+            }
+        }
+        block_sum2<BLOCK>(flow_sum, flow_n, s);
+    }
+    if (threadIdx.x == 0) {
+        const float optical_flow = flow_sum / flow_n;
+        const Iso pose = went_well ? iso_mul(kf_pose, iso_inverse(lm_model)) : prev_pose;  // inverse_compositional.rs:206-208
+        iso_store(pose, out_poses7 + 7 * pair);
+        out_status[pair] = went_well ? VORS_TRACK_OK : VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT;
+        if (out_stats) {
+            iso_store(lm_model, out_stats[pair].lm_model);
+            out_stats[pair].optical_flow = optical_flow;
+            out_stats[pair].change_keyframe = (optical_flow >= 1.0f) ? 1 : 0;
+        }
+    }
+    // usable candidates per level (diagnostics for the byte model)
+    if (out_stats) {
+        for (int lvl = 0; lvl < g.L; ++lvl) {
+            const LevelGeom lg = g.lv[lvl];
+            float n = 0.f, dummy = 0.f;
+            if constexpr (DENSE) {
+                if (lvl == 0) {
+                    const uint16_t* d = kf_depth + (size_t)pair * g.S0;
+                    for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (d[i] != 0) ? 1.0f : 0.f;
+                } else {
+                    const float* z = rec.IZ + (size_t)pair * g.slots_total + lg.slot_off;
+                    for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) {
+                        const float v = z[i];
+                        n += (v != v) ? 0.f : 1.0f;
+                    }
+                }
+            } else {
+                const float4* A = rec.A + (size_t)pair * g.slots_total + lg.slot_off;
+                for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (A[i].w >= 0.f) ? 1.0f : 0.f;
+            }
+            block_sum2<BLOCK>(n, dummy, s);
+            if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = (int)n;
+        }
+        if (threadIdx.x == 0)
+            for (int lvl = g.L; lvl < VORS_MAX_LEVELS; ++lvl) {
+                out_stats[pair].nb_iter[lvl] = 0;
+                out_stats[pair].n_points[lvl] = 0;
+                out_stats[pair].energy[lvl] = 0.f;
+            }
+    }
+}
+
+template <int BLOCK, bool DENSE>
+static void launch_lm_track_block(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                                  const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats,
+                                  int n_pairs, hipStream_t s) {
+    if (g.huber_delta > 0.f)
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, true, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0,
+                           kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats);
+    else
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, false, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0,
+                           kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats);
+}
+
+void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                     const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
+                     hipStream_t s) {
+#define VORS_LM_ARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, s
+    if (g.mode == VORS_CANDIDATES_DENSE) {
+        if (block >= 1024) launch_lm_track_block<1024, true>(VORS_LM_ARGS);
+        else if (block >= 512) launch_lm_track_block<512, true>(VORS_LM_ARGS);
+        else launch_lm_track_block<256, true>(VORS_LM_ARGS);
+    } else {
+        if (block >= 1024) launch_lm_track_block<1024, false>(VORS_LM_ARGS);
+        else if (block >= 512) launch_lm_track_block<512, false>(VORS_LM_ARGS);
+        else launch_lm_track_block<256, false>(VORS_LM_ARGS);
+    }
+#undef VORS_LM_ARGS
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Operator level (one pyramid level, explicit observations)
+// ------------------------------------------------------------------------------------------------------------
+#define OP_BLOCK 256
+__global__ void records_from_obs_kernel(Intr k, int rows, int cols, const uint8_t* __restrict__ tmpl, int n,
+                                        const int32_t* __restrict__ xy, const float* __restrict__ iz,
+                                        const float* __restrict__ jac, Records rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    const V3 P = back_project(k, (float)x, (float)y, 1.0f / iz[i]);
+    rec.A[i] = make_float4(P.x, P.y, P.z, (float)tmpl[(size_t)y * cols + x]);
+    rec.B[i] = make_float4(jac[6 * i], jac[6 * i + 1], jac[6 * i + 2], jac[6 * i + 3]);
+    rec.C[i] = make_float2(jac[6 * i + 4], jac[6 * i + 5]);
+    rec.XY[i] = (uint32_t)x | ((uint32_t)y << 16);
+    rec.IZ[i] = iz[i];
+}
+void launch_records_from_obs(Intr k, int rows, int cols, const uint8_t* tmpl, int n, const int32_t* xy, const float* iz,
+                             const float* jac, Records rec, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(records_from_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, k, rows, cols, tmpl, n, xy, iz, jac, rec);
+}
+
+template <bool HUBER>
+__global__ __launch_bounds__(OP_BLOCK) void lm_eval_obs_kernel(RecSrc src, int n, ImgCtx c, const float* __restrict__ model7,
+                                                                float* __restrict__ out, float* __restrict__ residuals) {
+    __shared__ LmShared s;
+    float acc[NACC];
+    const Iso model = iso_load(model7);
+    if (residuals)
+        eval_accumulate<OP_BLOCK, HUBER, true>(src, n, c, model, acc, residuals);
+    else
+        eval_accumulate<OP_BLOCK, HUBER, false>(src, n, c, model, acc, nullptr);
+    block_reduce<OP_BLOCK>(acc, s, 0);
+    if (threadIdx.x == 0) {
+        const float* a = s.sums[0];
+        out[0] = a[0] / a[1];
+        out[1] = a[1];
+        for (int q = 0; q < 6; ++q) out[2 + q] = a[2 + q];
+        int k = 8;
+        for (int q = 0; q < 6; ++q)
+            for (int r = q; r < 6; ++r) {
+                out[8 + q * 6 + r] = a[k];
+                out[8 + r * 6 + q] = a[k];
+                ++k;
+            }
+    }
+}
+static ImgCtx make_ctx(Intr k, int rows, int cols, const uint8_t* image, float huber) {
+    ImgCtx c;
+    c.img = image;
+    c.rows = rows;
+    c.cols = cols;
+    c.k = k;
+    c.huber = huber;
+    return c;
+}
+void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
+                        const float* model7, float* out, float* residuals, hipStream_t s) {
+    RecSrc src{rec.A, rec.B, rec.C};
+    if (huber_delta > 0.f)
+        hipLaunchKernelGGL(lm_eval_obs_kernel<true>, dim3(1), dim3(OP_BLOCK), 0, s, src, n, make_ctx(k, rows, cols, image, huber_delta),
+                           model7, out, residuals);
+    else
+        hipLaunchKernelGGL(lm_eval_obs_kernel<false>, dim3(1), dim3(OP_BLOCK), 0, s, src, n, make_ctx(k, rows, cols, image, huber_delta),
+                           model7, out, residuals);
+}
+
+template <bool HUBER>
+__global__ __launch_bounds__(OP_BLOCK) void lm_solve_obs_kernel(RecSrc src, int n, ImgCtx c, const float* __restrict__ model7,
+                                                                 float* __restrict__ out) {
+    __shared__ LmShared s;
+    Iso model = iso_load(model7);
+    int nb_iter = 0;
+    float energy = 0.f, lm_coef = 0.f;
+    const bool ok = solve_level<OP_BLOCK, HUBER>(src, n, c, &model, &nb_iter, &energy, &lm_coef, s);
+    if (threadIdx.x == 0) {
+        iso_store(model, out);
+        out[7] = (float)nb_iter;
+        out[8] = energy;
+        out[9] = lm_coef;
+        out[10] = ok ? 0.f : 1.f;
+    }
+}
+void launch_lm_solve_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
+                         const float* model7, float* out, hipStream_t s) {
+    RecSrc src{rec.A, rec.B, rec.C};
+    if (huber_delta > 0.f)
+        hipLaunchKernelGGL(lm_solve_obs_kernel<true>, dim3(1), dim3(OP_BLOCK), 0, s, src, n, make_ctx(k, rows, cols, image, huber_delta),
+                           model7, out);
+    else
+        hipLaunchKernelGGL(lm_solve_obs_kernel<false>, dim3(1), dim3(OP_BLOCK), 0, s, src, n, make_ctx(k, rows, cols, image, huber_delta),
+                           model7, out);
+}
+
+}  // namespace vors
