@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
 import numpy as np, torch
 import vors_amd as V
-V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", "libvors_hip_prof.so")
+V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", os.environ.get("VLIB", "libvors_hip_prof.so"))
 from oracle import oracle as O
 rows, cols, L = 480, 640, 6
 intr = O.scaled_intrinsics(rows, cols)

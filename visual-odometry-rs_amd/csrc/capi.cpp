@@ -142,6 +142,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.XY) (void)hipFree(b->rec.XY);
     if (b->rec.IZ) (void)hipFree(b->rec.IZ);
     if (b->rec.V) (void)hipFree(b->rec.V);
+    if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     for (int st = 0; st < 4; ++st) {
         for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
         for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
@@ -213,10 +214,30 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
     }
+    float2* lut = nullptr;
+    if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {
+        e = dmalloc(&lut, (size_t)65536, &b->bytes);
+        b->rec.LUT = lut;
+    }
     if (e != hipSuccess) {
         batch_free(b);
         return fail(VORS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
+    if (lut) launch_build_depth_lut(g.depth_scale, lut, nullptr);
+    // Fast exact division by the focal lengths: proven per divisor by exhaustive enumeration on the device, else disabled.
+    // Levels halve the focal lengths exactly (camera.rs:119-120), so the level-0 proof covers every level.
+    {
+        const float fu0 = g.lv[0].k.fu, fv0 = g.lv[0].k.fv;
+        const bool ok_u = !getenv("VORS_NO_FASTDIV") && verify_fastdiv(fu0, 1.0f / fu0, nullptr);
+        const bool ok_v = !getenv("VORS_NO_FASTDIV") && verify_fastdiv(fv0, 1.0f / fv0, nullptr);
+        for (int l = 0; l < g.L; ++l) {
+            const float fu = b->g.lv[l].k.fu, fv = b->g.lv[l].k.fv;
+            const bool pow2_u = (fu * (float)(1 << l) == fu0), pow2_v = (fv * (float)(1 << l) == fv0);
+            b->g.lv[l].fu = FastDiv{fu, 1.0f / fu, (ok_u && pow2_u) ? 1 : 0};
+            b->g.lv[l].fv = FastDiv{fv, 1.0f / fv, (ok_v && pow2_v) ? 1 : 0};
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
     *out = b;
     return VORS_OK;
 }
@@ -388,7 +409,7 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
         HIP_TRY(dC.alloc(n * 8));
         HIP_TRY(dXY.alloc(n * 4));
         HIP_TRY(dIZ.alloc(n * 4));
-        Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr};
+        Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr, nullptr};
         launch_dense_materialize(b->g, level, pair, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, out, nullptr);
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(A.data(), dA.p, n * sizeof(float4), hipMemcpyDeviceToHost));
@@ -662,7 +683,7 @@ static vors_status upload_obs(const vors_obs* o, const float model7[7], ObsDev& 
     }
     HIP_TRY(hipMemcpyAsync(d.model.p, model7, 28, hipMemcpyHostToDevice, s));
     d.k = Intr{o->cu, o->cv, o->fu, o->fv, o->skew};
-    d.rec = Records{d.A.as<float4>(), d.B.as<float4>(), d.C.as<float2>(), d.XY.as<uint32_t>(), d.IZ.as<float>(), nullptr};
+    d.rec = Records{d.A.as<float4>(), d.B.as<float4>(), d.C.as<float2>(), d.XY.as<uint32_t>(), d.IZ.as<float>(), nullptr, nullptr};
     launch_records_from_obs(d.k, o->rows, o->cols, d.tmpl.as<uint8_t>(), o->n, d.xy.as<int32_t>(), d.iz.as<float>(),
                             d.jac.as<float>(), d.rec, s);
     return VORS_OK;

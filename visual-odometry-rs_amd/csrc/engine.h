@@ -15,6 +15,7 @@ struct LevelGeom {
     int n_slots;        // candidate slots at this level (sparse: roots * 2^(L-1-l); dense: rows*cols)
     int slot_off;       // offset of this level's slots inside the per-pair planes (dense: IZ/V planes hold levels >= 1 only; -1 for level 0)
     Intr k;             // intrinsics of this level (camera.rs:106-123)
+    FastDiv fu, fv;     // verified fast exact division by the focal lengths of this level (lie.h)
 };
 
 // Everything a kernel needs to know about the batch layout. Passed by value.
@@ -42,6 +43,7 @@ struct Records {
     uint32_t* XY;
     float* IZ;
     float* V;  // dense mode only: fused weight ("variance") plane, < 0 = Unknown
+    const float2* LUT;  // dense mode only: depth u16 -> (scale / depth, 1 / (scale / depth)), exact
 };
 
 // Image pyramid of a batch: level 0 is the caller's buffer (zero copy), levels >= 1 live in `upper`.
@@ -69,6 +71,10 @@ void launch_lm_solve_obs(Intr k, int rows, int cols, const uint8_t* image, int n
 // Records from explicit (x, y, idepth, jac, template) arrays: operator-level entry.
 void launch_records_from_obs(Intr k, int rows, int cols, const uint8_t* tmpl, int n, const int32_t* xy, const float* iz,
                              const float* jac, Records rec, hipStream_t s);
+// Exhaustive device check of div_uniform for divisor d (all 2^23 significands); returns true when it is exact.
+bool verify_fastdiv(float d, float r, hipStream_t s);
+// depth -> (inverse depth, its reciprocal) table, 65536 float2 entries (dense mode, level 0).
+void launch_build_depth_lut(float depth_scale, float2* lut, hipStream_t s);
 void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5], double motion_scale,
                         int invalid_percent, uint8_t* kf_gray, uint16_t* kf_depth, uint8_t* cur_gray, uint16_t* cur_depth,
                         float* gt_models7, hipStream_t s);

@@ -15,6 +15,8 @@
 // Where fusing is harmless (accumulating the sums) explicit fmaf is used.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_common.h"
 #include "engine.h"
 #include "synth_scene.h"
@@ -113,12 +115,10 @@ __device__ __forceinline__ void write_record(const Records& rec, size_t slot, co
     rec.XY[slot] = (uint32_t)x | ((uint32_t)y << 16);
     rec.IZ[slot] = iz;
 }
+// An empty slot is recognised by tmpl < 0 alone; the other planes of an empty slot are never read.
 __device__ __forceinline__ void write_empty(const Records& rec, size_t slot) {
     rec.A[slot] = make_float4(0.f, 0.f, 0.f, -1.0f);
-    rec.B[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    rec.C[slot] = make_float2(0.f, 0.f);
     rec.XY[slot] = VORS_INVALID_XY;
-    rec.IZ[slot] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -132,47 +132,55 @@ __device__ __forceinline__ void write_empty(const Records& rec, size_t slot) {
 // (inverse_depth.rs:81-98; at most two known children per parent here, so the [a,b,c,d] order cannot matter).
 // ------------------------------------------------------------------------------------------------------------
 #define KF_WAVES 4
+// KF_R roots per wavefront: the early tree steps have only 4 * 2^k (node, child) items per root, so several roots share
+// a wavefront (more lanes busy, more independent loads in flight per wave, 1/KF_R as many waves).
+template <int KF_R>
 __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, const uint8_t* __restrict__ kf0,
                                                                          const uint8_t* __restrict__ kfu,
                                                                          const uint16_t* __restrict__ depth, Records rec) {
-    __shared__ uint32_t s_xy[KF_WAVES][256];
-    __shared__ uint32_t s_gr[KF_WAVES][256];
-    __shared__ float s_d[KF_WAVES][256];
-    __shared__ float s_v[KF_WAVES][256];
+    const int NODES = 1 << g.L;  // >= 2^L - 1 tree nodes per root
+    extern __shared__ __attribute__((aligned(16))) char kf_smem[];
+    uint32_t* s_xy = reinterpret_cast<uint32_t*>(kf_smem);  // [KF_WAVES][KF_R][NODES]
+    uint32_t* s_gr = s_xy + KF_WAVES * KF_R * NODES;
+    float* s_d = reinterpret_cast<float*>(s_gr + KF_WAVES * KF_R * NODES);
+    float* s_v = s_d + KF_WAVES * KF_R * NODES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.y;
     const int n_roots = g.root_rows * g.root_cols;
-    const int root = blockIdx.x * KF_WAVES + wave;
-    const bool active = root < n_roots;
+    const int root0 = (blockIdx.x * KF_WAVES + wave) * KF_R;  // first root of this wavefront
     const int L = g.L;
-    uint32_t* xy = s_xy[wave];
-    uint32_t* gr = s_gr[wave];
-    float* sd = s_d[wave];
-    float* sv = s_v[wave];
+    uint32_t* xy = s_xy + wave * KF_R * NODES;
+    uint32_t* gr = s_gr + wave * KF_R * NODES;
+    float* sd = s_d + wave * KF_R * NODES;
+    float* sv = s_v + wave * KF_R * NODES;
 
-    if (lane == 0) {
-        if (active) {
+    if (lane < KF_R) {
+        const int root = root0 + lane;
+        if (root < n_roots) {
             const int rx = root % g.root_cols, ry = root / g.root_cols;
             int gx, gy;
             grad_at(g, kf0, kfu, pair, L - 1, rx, ry, &gx, &gy);
-            xy[0] = (uint32_t)rx | ((uint32_t)ry << 16);
-            gr[0] = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
+            xy[lane * NODES] = (uint32_t)rx | ((uint32_t)ry << 16);
+            gr[lane * NODES] = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
         } else {
-            xy[0] = VORS_INVALID_XY;
-            gr[0] = 0;
+            xy[lane * NODES] = VORS_INVALID_XY;
+            gr[lane * NODES] = 0;
         }
     }
     __syncthreads();
 
-    // ---- top-down selection: level l -> l-1
+    // ---- top-down selection: level l -> l-1. Items = (root, node k, child c); the 4 children of a node sit in one quad.
     const uint32_t thresh = (uint32_t)g.thresh & 0xffffu;
     for (int l = L - 1; l >= 1; --l) {
         const int cap = 1 << (L - 1 - l);
         const int off = cap - 1, offc = 2 * cap - 1;
-        for (int base = 0; base < cap; base += 16) {
-            const int k = base + (lane >> 2), c = lane & 3;
-            const bool in = k < cap;
-            const uint32_t pxy = in ? xy[off + k] : VORS_INVALID_XY;
+        const int items = KF_R * cap * 4;
+        for (int base = 0; base < items; base += 64) {
+            const int t = base + lane;
+            const bool in = t < items;
+            const int rl = in ? (t >> 2) / cap : 0;  // root slot inside the wavefront
+            const int k = (t >> 2) - rl * cap, c = lane & 3;
+            const uint32_t pxy = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
             const bool pvalid = pxy != VORS_INVALID_XY;
             const int cx = 2 * (int)(pxy & 0xffffu) + (c >> 1), cy = 2 * (int)(pxy >> 16) + (c & 1);
             int gx = 0, gy = 0;
@@ -201,11 +209,11 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
                 const uint32_t cxy = (uint32_t)cx | ((uint32_t)cy << 16);
                 const uint32_t cg = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
                 if (myrank == 3) {
-                    xy[offc + 2 * k] = pvalid ? cxy : VORS_INVALID_XY;
-                    gr[offc + 2 * k] = cg;
+                    xy[rl * NODES + offc + 2 * k] = pvalid ? cxy : VORS_INVALID_XY;
+                    gr[rl * NODES + offc + 2 * k] = cg;
                 } else if (myrank == 2) {
-                    xy[offc + 2 * k + 1] = (pvalid && keep2) ? cxy : VORS_INVALID_XY;
-                    gr[offc + 2 * k + 1] = cg;
+                    xy[rl * NODES + offc + 2 * k + 1] = (pvalid && keep2) ? cxy : VORS_INVALID_XY;
+                    gr[rl * NODES + offc + 2 * k + 1] = cg;
                 }
             }
         }
@@ -215,15 +223,16 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     // ---- level 0: inverse depth from the depth map (inverse_depth.rs:24-29); unknown depth -> not a point
     {
         const int cap = 1 << (L - 1), off = cap - 1;
-        for (int k = lane; k < cap; k += 64) {
-            const uint32_t p = xy[off + k];
+        for (int t = lane; t < KF_R * cap; t += 64) {
+            const int rl = t / cap, k = t - rl * cap;
+            const uint32_t p = xy[rl * NODES + off + k];
             if (p != VORS_INVALID_XY) {
                 const uint16_t dz = depth[(size_t)pair * g.S0 + (size_t)(p >> 16) * g.lv[0].cols + (p & 0xffffu)];
                 if (dz == 0) {
-                    xy[off + k] = VORS_INVALID_XY;
+                    xy[rl * NODES + off + k] = VORS_INVALID_XY;
                 } else {
-                    sd[off + k] = g.depth_scale / (float)dz;
-                    sv[off + k] = g.idepth_variance;
+                    sd[rl * NODES + off + k] = g.depth_scale / (float)dz;
+                    sv[rl * NODES + off + k] = g.idepth_variance;
                 }
             }
         }
@@ -233,40 +242,51 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     for (int l = 1; l < L; ++l) {
         const int cap = 1 << (L - 1 - l);
         const int off = cap - 1, offc = 2 * cap - 1;
-        for (int k = lane; k < cap; k += 64) {
-            const bool k1 = xy[offc + 2 * k] != VORS_INVALID_XY, k2 = xy[offc + 2 * k + 1] != VORS_INVALID_XY;
+        for (int t = lane; t < KF_R * cap; t += 64) {
+            const int rl = t / cap, k = t - rl * cap;
+            const int c1 = rl * NODES + offc + 2 * k, c2 = c1 + 1, dst = rl * NODES + off + k;
+            const bool k1 = xy[c1] != VORS_INVALID_XY, k2 = xy[c2] != VORS_INVALID_XY;
             if (k1 && k2) {
-                const float d1 = sd[offc + 2 * k], v1 = sv[offc + 2 * k], d2 = sd[offc + 2 * k + 1], v2 = sv[offc + 2 * k + 1];
+                const float d1 = sd[c1], v1 = sv[c1], d2 = sd[c2], v2 = sv[c2];
                 const float sum = v1 + v2;
-                sd[off + k] = (d1 * v1 + d2 * v2) / sum;
-                sv[off + k] = sum;
+                sd[dst] = (d1 * v1 + d2 * v2) / sum;
+                sv[dst] = sum;
             } else if (k1 || k2) {
-                const int src = k1 ? offc + 2 * k : offc + 2 * k + 1;
-                sd[off + k] = sd[src];
-                sv[off + k] = sv[src];
+                const int src = k1 ? c1 : c2;
+                sd[dst] = sd[src];
+                sv[dst] = sv[src];
             } else {
-                xy[off + k] = VORS_INVALID_XY;
+                xy[dst] = VORS_INVALID_XY;
             }
         }
         __syncthreads();
     }
-    if (!active) return;
-    // ---- records
+    // ---- records. Slot layout [level][wavefront region][j]: the KF_R roots of a wavefront own KF_R * cap contiguous slots of
+    // each level; usable points are COMPACTED to the front of that region (fixed order: by root, then tree slot), the tail is
+    // marked empty. Whole wavefronts of the LM kernel then see either (almost) only points or only empty slots.
     for (int l = 0; l < L; ++l) {
         const int cap = 1 << (L - 1 - l), off = cap - 1;
         const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
-        const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off + (size_t)root * cap;
-        for (int k = lane; k < cap; k += 64) {
-            const uint32_t p = xy[off + k];
-            if (p != VORS_INVALID_XY) {
+        const int n_here = min(KF_R, max(0, n_roots - root0)) * cap;  // slots of this region that exist
+        const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off + (size_t)root0 * cap;
+        int filled = 0;  // wavefront-uniform running count of points written
+        for (int base = 0; base < KF_R * cap; base += 64) {
+            const int t = base + lane;
+            const int rl = t / cap, k = t - rl * cap;
+            const bool in = t < n_here;
+            const uint32_t p = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
+            const bool valid = p != VORS_INVALID_XY;
+            const unsigned long long m = __ballot(valid);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (valid) {
                 const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
-                const uint32_t gg = gr[off + k];
-                write_record(rec, slot0 + k, g.lv[l].k, x, y, sd[off + k], (int)(int16_t)(gg & 0xffffu), (int)(int16_t)(gg >> 16),
-                             img[(size_t)y * g.lv[l].cols + x]);
-            } else {
-                write_empty(rec, slot0 + k);
+                const uint32_t gg = gr[rl * NODES + off + k];
+                write_record(rec, slot0 + filled + before, g.lv[l].k, x, y, sd[rl * NODES + off + k], (int)(int16_t)(gg & 0xffffu),
+                             (int)(int16_t)(gg >> 16), img[(size_t)y * g.lv[l].cols + x]);
             }
+            filled += __popcll(m);
         }
+        for (int t = filled + lane; t < n_here; t += 64) write_empty(rec, slot0 + t);
     }
 }
 
@@ -388,9 +408,48 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         for (int l = 2; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {
-        dim3 grid((n_roots + KF_WAVES - 1) / KF_WAVES, n_pairs);
-        hipLaunchKernelGGL(keyframe_sparse_kernel, grid, dim3(64 * KF_WAVES), 0, s, g, kf.level0, kf.upper, depth, rec);
+        static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
+        const int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
+        dim3 grid((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r), n_pairs);
+        const size_t lds = (size_t)KF_WAVES * r * (1 << g.L) * 16;
+        if (r == 8) hipLaunchKernelGGL(keyframe_sparse_kernel<8>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 2) hipLaunchKernelGGL(keyframe_sparse_kernel<2>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else hipLaunchKernelGGL(keyframe_sparse_kernel<1>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Exactness proof-by-enumeration for div_uniform (lie.h) and the depth lookup table of the dense LM source.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void verify_fastdiv_kernel(float d, float r, int* mismatch) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 2^23 significands
+    if (m >= (1u << 23)) return;
+    const FastDiv f{d, r, 1};
+    // one binade with a large and one with a small exponent (both scale exactly; two are checked for good measure)
+    const float x1 = __int_as_float((int)(0x3f800000u | m)), x2 = __int_as_float((int)(0x4b000000u | m));
+    const bool bad = (div_uniform<true>(x1, f) != x1 / d) || (div_uniform<true>(-x1, f) != (-x1) / d) || (div_uniform<true>(x2, f) != x2 / d);
+    if (bad) atomicExch(mismatch, 1);
+}
+bool verify_fastdiv(float d, float r, hipStream_t s) {
+    if (!(d == d) || d == 0.0f || !(r == r) || fabsf(d) > 1e30f || fabsf(d) < 1e-30f) return false;
+    int* flag = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)) != hipSuccess) return false;
+    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+    hipLaunchKernelGGL(verify_fastdiv_kernel, dim3((1u << 23) / 256), dim3(256), 0, s, d, r, flag);
+    int h = 1;
+    const bool ok = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(flag);
+    return ok && h == 0;
+}
+__global__ void build_depth_lut_kernel(float depth_scale, float2* lut) {
+    const int dz = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dz >= 65536) return;
+    const float iz = depth_scale / (float)dz;  // inverse_depth.rs:24-29 (dz = 0 is never used: the pixel is Unknown)
+    lut[dz] = make_float2(iz, 1.0f / iz);      // lm_optimizer.rs:215: back_project(.., 1.0 / _z)
+}
+void launch_build_depth_lut(float depth_scale, float2* lut, hipStream_t s) {
+    hipLaunchKernelGGL(build_depth_lut_kernel, dim3(256), dim3(256), 0, s, depth_scale, lut);
 }
 
 // ------------------------------------------------------------------------------------------------------------

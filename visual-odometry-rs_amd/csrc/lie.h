@@ -199,6 +199,52 @@ VORS_HD void warp_jacobian_at(float gu, float gv, float u, float v, float _z, co
     J[5] = gu * (-k.fu * k.fu * b + k.skew * c) * _fuv + gv * (c / k.fu);
 }
 
+// Division by a value that is uniform over a level (the focal lengths): x / d == fma(fma(-q, d, x), r, q) with r = RN(1/d),
+// q = RN(x r), whenever `ok` — and `ok` is only set after the identity has been checked EXHAUSTIVELY for this d over all 2^23
+// significands of x on the device (kernels.hip, verify_fastdiv_kernel): both sides scale exactly with the exponent of x and
+// are odd in x, so one binade proves every finite x whose quotient stays in the normal range. Otherwise: IEEE division.
+struct FastDiv {
+    float d, r;
+    int ok;
+};
+template <bool FAST>
+VORS_HD float div_uniform(float x, const FastDiv& f) {
+    if (FAST) {
+        const float q = x * f.r;
+        const float e = fmaf(-q, f.d, x);
+        const float q1 = fmaf(e, f.r, q);
+        return x == 0.0f ? x * f.r : q1;  // keeps the sign of a zero quotient
+    }
+    return x / f.d;
+}
+struct IntrFast {
+    Intr k;
+    FastDiv fu, fv;
+};
+// back_project with the two divisions by fv / fu through div_uniform (bit-identical to back_project by construction).
+template <bool FAST>
+VORS_HD V3 back_project_fast(const IntrFast& kf, float px, float py, float depth) {
+    const float z = depth;
+    const float y = div_uniform<FAST>((py - kf.k.cv) * z, kf.fv);
+    const float x = div_uniform<FAST>((px - kf.k.cu) * z - kf.k.skew * y, kf.fu);
+    return V3{x, y, z};
+}
+template <bool FAST>
+VORS_HD void warp_jacobian_at_fast(float gu, float gv, float u, float v, float _z, const IntrFast& kf, float J[6]) {
+    const Intr& k = kf.k;
+    const float a = u - k.cu;
+    const float b = v - k.cv;
+    const float c = a * k.fv - k.skew * b;
+    const float _fv = 1.0f / k.fv;
+    const float _fuv = 1.0f / (k.fu * k.fv);
+    J[0] = gu * _z * k.fu;
+    J[1] = _z * (gu * k.skew + gv * k.fv);
+    J[2] = -_z * (gu * a + gv * b);
+    J[3] = gu * (-a * b * _fv - k.skew) + gv * (-b * b * _fv - k.fv);
+    J[4] = gu * (a * c * _fuv + k.fu) + gv * (b * c * _fuv);
+    J[5] = gu * (-k.fu * k.fu * b + k.skew * c) * _fuv + gv * div_uniform<FAST>(c, kf.fu);
+}
+
 // so3 / se3 log: API parity only (src/math/so3.rs:81-99, src/math/se3.rs:99-129); host use.
 inline void so3_log(const Quat& r, float w[3]) {
     const V3 imag{r.i, r.j, r.k};

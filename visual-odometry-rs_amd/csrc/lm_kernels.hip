@@ -34,6 +34,9 @@ struct LmShared {
     float misc[LM_MAX_WAVES * 2];
 };
 
+// d / 2 with truncation toward zero (Rust's `/` on i16, gradient.rs:28-29,79,92), branch-free.
+__device__ __forceinline__ int half_trunc(int d) { return (d + (int)((unsigned)d >> 31)) >> 1; }
+
 // A candidate point ready for warping: back-projected keyframe point + template grey level (< 0 = empty slot).
 struct Pos {
     float X, Y, Z;  // camera.rs:135-140 applied to (x, y, 1/_z)
@@ -49,6 +52,8 @@ struct Pos {
 // ---- point source: stored record planes (sparse mode, operator level). G = 2 slots (i, i + BLOCK).
 struct RecSrc {
     static constexpr int G = 2;
+    static constexpr bool PREFETCH = false;
+    static constexpr bool SKIP_EMPTY = true;
     const float4* A;
     const float4* B;
     const float2* C;
@@ -87,12 +92,9 @@ struct RecSrc {
 #pragma unroll
         for (int g = 0; g < 2; ++g) p[g] = Pos{r.a[g].x, r.a[g].y, r.a[g].z, r.a[g].w};
     }
-    __device__ __forceinline__ void jacobians(const Raw& r, float J[2][6]) const {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            J[g][0] = r.b[g].x; J[g][1] = r.b[g].y; J[g][2] = r.b[g].z; J[g][3] = r.b[g].w;
-            J[g][4] = r.c[g].x; J[g][5] = r.c[g].y;
-        }
+    __device__ __forceinline__ void jacobian(const Raw& r, int g, float J[6]) const {
+        J[0] = r.b[g].x; J[1] = r.b[g].y; J[2] = r.b[g].z; J[3] = r.b[g].w;
+        J[4] = r.c[g].x; J[5] = r.c[g].y;
     }
     __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.i[g] < n ? r.i[g] : -1; }
 };
@@ -107,6 +109,8 @@ struct RecSrc {
 template <bool LEVEL0>
 struct DenseSrc {
     static constexpr int G = 1;
+    static constexpr bool PREFETCH = false;
+    static constexpr bool SKIP_EMPTY = false;
     const uint8_t* kimg;    // keyframe image of this level
     const uint8_t* kfine;   // next finer keyframe level (levels >= 1)
     const uint16_t* depth;  // level 0
@@ -167,30 +171,37 @@ struct DenseSrc {
         const V3 P = back_project(k, (float)r.x, (float)r.y, 1.0f / r.izv);
         p[0] = Pos{P.x, P.y, P.z, r.valid ? (float)r.tm : -1.0f};
     }
-    __device__ __forceinline__ void jacobians(const Raw& r, float J[1][6]) const {
-        warp_jacobian_at((float)r.gx, (float)r.gy, (float)r.x, (float)r.y, r.izv, k, J[0]);
+    __device__ __forceinline__ void jacobian(const Raw& r, int, float J[6]) const {
+        warp_jacobian_at((float)r.gx, (float)r.gy, (float)r.x, (float)r.y, r.izv, k, J);
     }
     __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.i; }
 };
 
 // DenseQuadSrc: FOUR horizontally adjacent pixels per unit (cols % 4 == 0). One dword / dwordx2 / dwordx4 load per image
 // row and plane instead of ~8 byte loads per pixel: coalesced 256 B - 1 KiB per wavefront instruction, 4-way ILP per lane.
-template <bool LEVEL0>
+template <bool LEVEL0, bool FAST>
 struct DenseQuadSrc {
     static constexpr int G = 4;
+    static constexpr bool PREFETCH = false;
+    static constexpr bool SKIP_EMPTY = false;
     const uint8_t* kimg;
     const uint8_t* kfine;
     const uint16_t* depth;
     const float* iz;
     int rows, cols, fcols, qcols;  // qcols = cols / 4
-    Intr k;
-    float depth_scale;
+    IntrFast kf;
+    const float2* lut;  // level 0: depth -> (inverse depth, 1 / inverse depth), exact table
     struct Cursor {
         int i, qx, y;  // i = quad index
     };
+    struct Loaded {  // raw words of one quad, straight from memory (kept in flight one iteration ahead)
+        uint32_t cw, w1, w2, w3, w4;  // level 0: centre/up/down rows + left/right bytes; levels >= 1: fine rows (2 x uint2) + unused
+        uint32_t d0, d1, d2, d3;      // level 0: depth (uint2) ; levels >= 1: inverse depths (float4 bits)
+        int x0, y;
+    };
     struct Raw {
         int x0, y;
-        float izv[4];
+        float izv[4], zv[4];
         int gx[4], gy[4], tm[4];
         bool valid[4];
     };
@@ -210,66 +221,86 @@ struct DenseQuadSrc {
         }
         return Cursor{c.i + BLOCK, qx, y};
     }
-    template <int BLOCK>
-    __device__ __forceinline__ void fetch(const Cursor& c, int n, Raw& r) const {
+    __device__ __forceinline__ void load(const Cursor& c, Loaded& r) const {
         const int x0 = 4 * c.qx, y = c.y;
         r.x0 = x0;
         r.y = y;
         const uint8_t* row = kimg + (size_t)y * cols + x0;
-        const uint32_t cw = *reinterpret_cast<const uint32_t*>(row);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.tm[j] = (cw >> (8 * j)) & 0xff;
+        r.cw = *reinterpret_cast<const uint32_t*>(row);
         if (LEVEL0) {
-            // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33)
             const bool yin = y > 0 && y < rows - 1;
-            const uint32_t uw = *reinterpret_cast<const uint32_t*>(row - (yin ? cols : 0));
-            const uint32_t dw = *reinterpret_cast<const uint32_t*>(row + (yin ? cols : 0));
-            const int lft = row[x0 > 0 ? -1 : 0];
-            const int rgt = row[x0 + 4 < cols ? 4 : 3];
+            r.w1 = *reinterpret_cast<const uint32_t*>(row - (yin ? cols : 0));
+            r.w2 = *reinterpret_cast<const uint32_t*>(row + (yin ? cols : 0));
+            r.w3 = row[x0 > 0 ? -1 : 0];
+            r.w4 = row[x0 + 4 < cols ? 4 : 3];
             const uint2 dzw = *reinterpret_cast<const uint2*>(depth + (size_t)y * cols + x0);
-            const int b[6] = {lft, r.tm[0], r.tm[1], r.tm[2], r.tm[3], rgt};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = x0 + j;
-                const bool xin = x > 0 && x < cols - 1;
-                const int up = (uw >> (8 * j)) & 0xff, dn = (dw >> (8 * j)) & 0xff;
-                r.gx[j] = (xin && yin) ? (b[j + 2] - b[j]) / 2 : 0;
-                r.gy[j] = (xin && yin) ? (dn - up) / 2 : 0;
-                const int dz = (j < 2 ? (dzw.x >> (16 * j)) : (dzw.y >> (16 * (j - 2)))) & 0xffff;
-                r.valid[j] = dz != 0;
-                r.izv[j] = depth_scale / (float)dz;
-            }
+            r.d0 = dzw.x;
+            r.d1 = dzw.y;
+            r.d2 = r.d3 = 0;
         } else {
-            // 2x2 block gradients of the next finer level (gradient.rs:74-93): pixels (2y, 2x0 .. 2x0+7) and the row below
             const uint8_t* f = kfine + (size_t)(2 * y) * fcols + 2 * x0;
             const uint2 f0 = *reinterpret_cast<const uint2*>(f);
             const uint2 f1 = *reinterpret_cast<const uint2*>(f + fcols);
-            const float4 z4 = *reinterpret_cast<const float4*>(iz + (size_t)y * cols + x0);
-            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+            r.w1 = f0.x; r.w2 = f0.y; r.w3 = f1.x; r.w4 = f1.y;
+            const uint4 z4 = *reinterpret_cast<const uint4*>(iz + (size_t)y * cols + x0);
+            r.d0 = z4.x; r.d1 = z4.y; r.d2 = z4.z; r.d3 = z4.w;
+        }
+    }
+    __device__ __forceinline__ void decode(const Loaded& l, Raw& r) const {
+        const int x0 = l.x0, y = l.y;
+        r.x0 = x0;
+        r.y = y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.tm[j] = (l.cw >> (8 * j)) & 0xff;
+        if (LEVEL0) {
+            // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33)
+            const int yin = (y > 0 && y < rows - 1) ? -1 : 0;
+            const int b[6] = {(int)l.w3, r.tm[0], r.tm[1], r.tm[2], r.tm[3], (int)l.w4};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t w0 = j < 2 ? f0.x : f0.y, w1 = j < 2 ? f1.x : f1.y;
+                const int x = x0 + j;
+                const int in = yin & ((x > 0 && x < cols - 1) ? -1 : 0);  // all-ones inside, 0 on the 1-px border
+                const int up = (l.w1 >> (8 * j)) & 0xff, dn = (l.w2 >> (8 * j)) & 0xff;
+                r.gx[j] = half_trunc(b[j + 2] - b[j]) & in;  // masks, not branches: keeps the loop one basic block
+                r.gy[j] = half_trunc(dn - up) & in;
+                const int dz = (j < 2 ? (l.d0 >> (16 * j)) : (l.d1 >> (16 * (j - 2)))) & 0xffff;
+                r.valid[j] = dz != 0;
+                const float2 zl = lut[dz];  // (scale / dz, 1 / (scale / dz)): inverse_depth.rs:24-29, lm_optimizer.rs:215
+                r.izv[j] = zl.x;
+                r.zv[j] = zl.y;
+            }
+        } else {
+            // 2x2 block gradients of the next finer level (gradient.rs:74-93)
+            const uint32_t zz[4] = {l.d0, l.d1, l.d2, l.d3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w0 = j < 2 ? l.w1 : l.w2, w1 = j < 2 ? l.w3 : l.w4;
                 const int sh = (j & 1) * 16;
                 const int a = (w0 >> sh) & 0xff, cc = (w0 >> (sh + 8)) & 0xff;
                 const int bb = (w1 >> sh) & 0xff, d = (w1 >> (sh + 8)) & 0xff;
-                r.gx[j] = (cc + d - a - bb) / 2;
-                r.gy[j] = (bb - a + d - cc) / 2;
-                r.izv[j] = zz[j];
-                r.valid[j] = !(zz[j] != zz[j]);
+                r.gx[j] = half_trunc(cc + d - a - bb);
+                r.gy[j] = half_trunc(bb - a + d - cc);
+                r.izv[j] = __int_as_float((int)zz[j]);
+                r.zv[j] = 1.0f / r.izv[j];
+                r.valid[j] = !(r.izv[j] != r.izv[j]);
             }
         }
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const Cursor& c, int n, Raw& r) const {
+        Loaded l;
+        load(c, l);
+        decode(l, r);
     }
     __device__ __forceinline__ void positions(const Raw& r, Pos p[4]) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const V3 P = back_project(k, (float)(r.x0 + j), (float)r.y, 1.0f / r.izv[j]);
+            const V3 P = back_project_fast<FAST>(kf, (float)(r.x0 + j), (float)r.y, r.zv[j]);
             p[j] = Pos{P.x, P.y, P.z, r.valid[j] ? (float)r.tm[j] : -1.0f};
         }
     }
-    __device__ __forceinline__ void jacobians(const Raw& r, float J[4][6]) const {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            warp_jacobian_at((float)r.gx[j], (float)r.gy[j], (float)(r.x0 + j), (float)r.y, r.izv[j], k, J[j]);
+    __device__ __forceinline__ void jacobian(const Raw& r, int j, float J[6]) const {
+        warp_jacobian_at_fast<FAST>((float)r.gx[j], (float)r.gy[j], (float)(r.x0 + j), (float)r.y, r.izv[j], kf, J);
     }
     __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.y * cols + r.x0 + g; }
 };
@@ -294,7 +325,8 @@ __device__ __forceinline__ Warped warp_point(const ImgCtx& c, const Iso& model, 
     w.uf = floorf(w.u);
     w.vf = floorf(w.v);
     w.inside = (p.tmpl >= 0.f) && (w.uf >= 0.f) && (w.uf < (float)(c.cols - 2)) && (w.vf >= 0.f) && (w.vf < (float)(c.rows - 2));
-    w.off = w.inside ? (int)w.vf * c.cols + (int)w.uf : 0;
+    // masked, not branched (an outside point reads the safe address 0 and is selected away later)
+    w.off = (__float2int_rz(w.vf) * c.cols + __float2int_rz(w.uf)) & (w.inside ? -1 : 0);
     return w;
 }
 struct Taps {
@@ -352,33 +384,75 @@ __device__ __forceinline__ Iso iso_uniform(const Iso& m) {
     return Iso{V3{uniform_f(m.t.x), uniform_f(m.t.y), uniform_f(m.t.z)}, Quat{uniform_f(m.q.i), uniform_f(m.q.j), uniform_f(m.q.k), uniform_f(m.q.w)}};
 }
 
+// The per-group body shared by both loop shapes: warp all G points, issue all taps, then Jacobians + sums two points at a
+// time (keeps the live Jacobian registers at 12 while the tap loads are in flight).
+template <bool HUBER, bool WRITE_RES, class Src>
+__device__ __forceinline__ void process_group(const Src& src, const typename Src::Raw& raw, int n_units, const ImgCtx& c,
+                                              const Iso& model, float acc[NACC], float* residuals) {
+    constexpr int G = Src::G;
+    Pos pos[G];
+    src.positions(raw, pos);
+    if (Src::SKIP_EMPTY && !WRITE_RES) {  // a wavefront whose group holds no candidate at all (compacted empty tail) skips the arithmetic
+        bool any_valid = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) any_valid = any_valid || (pos[g].tmpl >= 0.f);
+        if (!__any(any_valid)) return;
+    }
+    Warped w[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) w[g] = warp_point(c, model, pos[g]);
+    Taps t[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t[g] = load_taps(c, w[g]);
+#pragma unroll
+    for (int g0 = 0; g0 < G; g0 += 2) {
+        float J[2][6];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (g0 + h < G) src.jacobian(raw, g0 + h, J[h]);  // independent of the taps: overlaps their latency
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (g0 + h < G) {
+                const int g = g0 + h;
+                const float res = accumulate_point<HUBER>(c, pos[g].tmpl, J[h], w[g], t[g], acc);
+                if (WRITE_RES) {
+                    const int sl = src.slot(raw, g, n_units);
+                    if (sl >= 0) residuals[sl] = res;
+                }
+            }
+    }
+}
+
 // One evaluation sweep over the units of a level: each thread accumulates its strided share, Src::G points in flight.
+// Sources with PREFETCH keep the raw words of the NEXT unit in flight while the current one is processed, so the wavefronts
+// of a SIMD do not all stall on the same loads at the top of every iteration.
 template <int BLOCK, bool HUBER, bool WRITE_RES, class Src>
 __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, const ImgCtx& c, const Iso& model, float acc[NACC],
                                                 float* residuals) {
-    constexpr int G = Src::G;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
-    for (typename Src::Cursor cur = src.template begin<BLOCK>(); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
-        typename Src::Raw raw;
-        src.template fetch<BLOCK>(cur, n_units, raw);
-        Pos pos[G];
-        src.positions(raw, pos);
-        Warped w[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) w[g] = warp_point(c, model, pos[g]);
-        Taps t[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) t[g] = load_taps(c, w[g]);
-        float J[G][6];
-        src.jacobians(raw, J);  // independent of the taps: overlaps their latency
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float res = accumulate_point<HUBER>(c, pos[g].tmpl, J[g], w[g], t[g], acc);
-            if (WRITE_RES) {
-                const int sl = src.slot(raw, g, n_units);
-                if (sl >= 0) residuals[sl] = res;
-            }
+    if constexpr (Src::PREFETCH) {
+        typename Src::Cursor cur = src.template begin<BLOCK>();
+        if (cur.i >= n_units) return;
+        typename Src::Loaded ld;
+        src.load(cur, ld);
+        for (;;) {
+            const typename Src::Cursor nxt = src.template advance<BLOCK>(cur);
+            const bool more = nxt.i < n_units;
+            typename Src::Loaded ld_next = ld;
+            if (more) src.load(nxt, ld_next);
+            typename Src::Raw raw;
+            src.decode(ld, raw);
+            process_group<HUBER, WRITE_RES>(src, raw, n_units, c, model, acc, residuals);
+            if (!more) break;
+            ld = ld_next;
+            cur = nxt;
+        }
+    } else {
+        for (typename Src::Cursor cur = src.template begin<BLOCK>(); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
+            typename Src::Raw raw;
+            src.template fetch<BLOCK>(cur, n_units, raw);
+            process_group<HUBER, WRITE_RES>(src, raw, n_units, c, model, acc, residuals);
         }
     }
 }
@@ -528,8 +602,13 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
         if (lvl == 0) {
             if constexpr (QUADS) {
                 if (quad_ok) {
-                    DenseQuadSrc<true> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, lg.k, g.depth_scale};
-                    f(src, lg.rows * (lg.cols / 4));
+                    if (lg.fu.ok && lg.fv.ok) {  // workgroup-uniform: selects the instantiation, no branch in the hot loop
+                        DenseQuadSrc<true, true> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT};
+                        f(src, lg.rows * (lg.cols / 4));
+                    } else {
+                        DenseQuadSrc<true, false> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT};
+                        f(src, lg.rows * (lg.cols / 4));
+                    }
                     return;
                 }
             }
@@ -538,8 +617,13 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
         } else {
             if constexpr (QUADS) {
                 if (quad_ok) {
-                    DenseQuadSrc<false> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, lg.k, g.depth_scale};
-                    f(src, lg.rows * (lg.cols / 4));
+                    if (lg.fu.ok && lg.fv.ok) {
+                        DenseQuadSrc<false, true> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT};
+                        f(src, lg.rows * (lg.cols / 4));
+                    } else {
+                        DenseQuadSrc<false, false> src{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT};
+                        f(src, lg.rows * (lg.cols / 4));
+                    }
                     return;
                 }
             }
