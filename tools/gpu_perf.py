@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
 import numpy as np, torch
 import vors_amd as V
+if os.environ.get("VLIB"): V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", os.environ["VLIB"])
 from oracle import oracle as O
 
 rows, cols, L = 480, 640, 6

@@ -197,7 +197,9 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     b->cfg = *cfg;
     b->g = g;
     b->max_pairs = max_pairs;
-    b->lm_block = 1024;
+    // Threads per frame pair in the LM kernel. Few pairs: one big workgroup per CU (latency); many pairs: 256-thread
+    // workgroups, several per CU, so that pairs with different iteration counts balance (measured).
+    b->lm_block = max_pairs >= 512 ? 256 : (g.mode == VORS_CANDIDATES_DENSE ? 1024 : 512);
     if (const char* e = getenv("VORS_LM_BLOCK")) b->lm_block = atoi(e);  // tuning knob (256 / 512 / 1024)
     const size_t np = (size_t)max_pairs;
     const size_t slots = np * (size_t)g.slots_total;
