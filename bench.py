@@ -60,6 +60,18 @@ def byte_model(stats, L, rows, cols, dense):
     return b_io, b_lm, float(evals.sum(1).mean()), float((evals * n_pts).sum(1).mean())
 
 
+def lm_traffic(args):
+    """HBM bytes per lm_track_kernel launch measured with rocprofv3 PMC passes (profiles/lm_traffic.json), or None when no
+    profile of this exact workload has been committed."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "lm_traffic.json")))
+    except Exception:
+        return None
+    key = f"{args.candidates}_{args.cols}x{args.rows}_L{args.levels}_{args.pairs}pairs"
+    e = table.get(key)
+    return int(e["traffic_bytes"]) if e and args.huber == 0.0 else None
+
+
 class Workload:
     def __init__(self, V, args, mode, device, seed0):
         self.V, self.args, self.mode = V, args, mode
@@ -181,7 +193,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
-            "traffic": None,  # PMC FETCH/WRITE bytes per launch: see profiles/ (collected in separate rocprofv3 --pmc passes)
+            "traffic": lm_traffic(args),  # PMC FETCH/WRITE bytes per launch from the committed rocprofv3 passes (profiles/)
             "algorithmic_bytes_per_launch": lm_bytes,
             "kernel_ms_avg": round(lm_avg_s * 1e3, 5),
             "whole_job_GBps": round(job_gbps, 2),
