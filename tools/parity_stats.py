@@ -1,0 +1,25 @@
+"""Distribution of |pose_gpu - pose_oracle| over many pairs (how often an LM accept/reject flip matters). Development aid."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
+import numpy as np, torch
+import vors_amd as V
+from oracle import oracle as O
+rows, cols, L = 480, 640, 6
+intr = O.scaled_intrinsics(rows, cols)
+for mode, n in ((0, 512), (1, 96)):
+    kg, kd, cg, _, gt = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode)
+    b = V.Batch(cfg, n, rows, cols)
+    poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(n)
+    b.track_pairs(kg, kd, cg, poses, status, stats); torch.cuda.synchronize()
+    t0 = time.time()
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg.cpu().numpy(), kd.cpu().numpy().view(np.uint16), cg.cpu().numpy(), n_threads=os.cpu_count())
+    st = V.decode_stats(stats)
+    err = np.abs(poses.cpu().numpy() - ref["poses"]).max(axis=1)
+    same_it = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1)
+    q = np.quantile(err, [0.5, 0.9, 0.99, 1.0])
+    print(f"mode {mode} n {n}: |pose diff| median {q[0]:.2e} p90 {q[1]:.2e} p99 {q[2]:.2e} max {q[3]:.2e}; >1e-5: {(err>1e-5).sum()} >1e-4: {(err>1e-4).sum()}; "
+          f"identical iteration counts {same_it.mean():.1%}; status equal {(status.cpu().numpy()==ref['status']).all()}; oracle {time.time()-t0:.1f}s")
+    bad = np.argsort(-err)[:3]
+    for i in bad: print("   pair", i, "err", err[i], "gpu iters", st["nb_iter"][i][:L], "oracle", ref["nb_iter"][i])
