@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--huber", type=float, default=0.0)
     p.add_argument("--cpu-pairs", type=int, default=-1, help="pairs timed on the CPU oracle (-1 = auto, 0 = skip)")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary (other candidate mode) measurement")
+    p.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (kernel timing off)")
     return p.parse_args()
 
 
@@ -87,9 +88,24 @@ class Workload:
         self.poses = torch.zeros((n, 7), dtype=torch.float32, device=device)
         self.status = torch.zeros(n, dtype=torch.int32, device=device)
         self.stats = V.stats_tensor(n, device=device)
+        self.graph = None
 
     def step(self):
-        self.batch.track_pairs(self.kg, self.kd, self.cg, self.poses, self.status, self.stats)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.batch.track_pairs(self.kg, self.kd, self.cg, self.poses, self.status, self.stats)
+
+    def capture(self):
+        """Capture one step into a HIP graph (the launches are purely stream-ordered)."""
+        self.step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                self.batch.track_pairs(self.kg, self.kd, self.cg, self.poses, self.status, self.stats)
+        self.graph = g
 
 
 def timed_run(work, steps, warmup, world, gathered):
@@ -146,8 +162,17 @@ def main():
     gathered = torch.zeros((world * args.pairs, 7), dtype=torch.float32, device=device) if world > 1 else None
 
     ring = min(max(args.steps, 1), 4096)
-    main_w.batch.enable_kernel_timing(ring)
-    dt = timed_run(main_w, args.steps, args.warmup, world, gathered)
+    if args.graph:
+        main_w.capture()
+        dt = timed_run(main_w, args.steps, args.warmup, world, gathered)
+        main_w.graph = None
+        main_w.batch.enable_kernel_timing(ring)   # kernel durations from a few eager steps after the timed region
+        for _ in range(min(args.steps, 5)):
+            main_w.step()
+        torch.cuda.synchronize()
+    else:
+        main_w.batch.enable_kernel_timing(ring)
+        dt = timed_run(main_w, args.steps, args.warmup, world, gathered)
     lm_ms = main_w.batch.kernel_times("lm")[-args.steps:]
     kf_ms = main_w.batch.kernel_times("keyframe")[-args.steps:]
     pyr_ms = main_w.batch.kernel_times("pyramid_keyframe")[-args.steps:] + main_w.batch.kernel_times("pyramid_current")[-args.steps:]
@@ -185,6 +210,7 @@ def main():
             "candidates": "dense (all-true level-0 mask, extension)" if dense else "coarse_to_fine (reference selection)",
             "huber_delta": args.huber,
             "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of poses per step" if world > 1 else "1 GPU",
+            "launch": "hipGraph replay" if args.graph else "eager",
         },
         "roofline": {
             "bound": "hbm",

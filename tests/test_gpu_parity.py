@@ -343,3 +343,51 @@ def test_config5_1280x960_7_levels_huber():
         assert (status == ref["status"]).all()
         assert (stats["n_points"][:, :L] == ref["n_points"]).all()
         assert np.abs(poses - ref["poses"]).max() < POSE_TOL
+
+
+def test_batch_keyframe_reuse_and_stream_capture():
+    """prepare_keyframes once, track_current many times (the keyframe data persists in the handle); and the whole step is
+    capturable into a HIP graph (only stream-ordered launches, no allocation or synchronisation inside)."""
+    import torch
+    rows, cols, L, n = 120, 160, 4, 6
+    intr = O.scaled_intrinsics(rows, cols)
+    step = np.array([0.006, -0.003, 0.002, 0.001, -0.0015, 0.0008])
+    frames = [[O.synth_frame(900 + i, step * k, rows, cols, intr, frame_salt=k) for k in range(4)] for i in range(n)]
+    kg = np.stack([f[0][0] for f in frames]); kd = np.stack([f[0][1] for f in frames])
+    cfg = vcfg(L, intr)
+    b = V.Batch(cfg, n, rows, cols)
+    t_kg, t_kd, _ = to_dev(kg, kd, kg)
+    b.prepare_keyframes(t_kg, t_kd)
+    trackers = [O.Tracker(O.make_config(L, intr), 0.0, frames[i][0][1], 0.0, frames[i][0][0]) for i in range(n)]
+    prev = torch.zeros((n, 7), device="cuda"); prev[:, 6] = 1.0
+    for k in range(1, 4):
+        cur = torch.from_numpy(np.stack([f[k][0] for f in frames])).cuda()
+        poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
+        stats = V.stats_tensor(n)
+        b.track_current(cur, poses, status, stats, prev_poses7=prev)
+        torch.cuda.synchronize()
+        st = V.decode_stats(stats)
+        for i in range(n):
+            ost = trackers[i].track(float(k), frames[i][k][1], float(k), frames[i][k][0])
+            assert not trackers[i].last()["changed_keyframe"], "the test trajectory must stay on the first keyframe"
+            assert ost == int(status[i])
+            assert np.abs(poses[i].cpu().numpy() - trackers[i].current_frame()[1]).max() < POSE_TOL
+        assert (st["change_keyframe"] == 0).all()
+        prev = poses.clone()
+    # graph capture of a full pairs step
+    cur = torch.from_numpy(np.stack([f[1][0] for f in frames])).cuda()
+    poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    b.track_pairs(t_kg, t_kd, cur, poses, status)
+    torch.cuda.synchronize()
+    expect = poses.clone()
+    poses.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            b.track_pairs(t_kg, t_kd, cur, poses, status)
+    for _ in range(3):
+        poses.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert (bits(poses.cpu().numpy()) == bits(expect.cpu().numpy())).all()
