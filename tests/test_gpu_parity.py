@@ -149,14 +149,16 @@ def test_lm_solve_and_host_driven_trait_vs_oracle():
         model = m_or
 
 
-def test_tracker_sequence_with_keyframe_switch_vs_oracle():
-    """Config::init + repeated Tracker::track along a trajectory long enough to force keyframe changes."""
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tracker_sequence_with_keyframe_switch_vs_oracle(mode):
+    """Config::init + repeated Tracker::track along a trajectory long enough to force keyframe changes
+    (mode 1 = dense extension: the keyframe's depth map stays resident and is re-read by the LM kernel)."""
     rows, cols, L = 120, 160, 4
     intr = O.scaled_intrinsics(rows, cols)
     step = np.array([0.012, -0.006, 0.004, 0.002, -0.003, 0.001])
     frames = [O.synth_frame(77, step * k, rows, cols, intr, frame_salt=k) for k in range(12)]
-    ot = O.Tracker(O.make_config(L, intr), 0.0, frames[0][1], 0.0, frames[0][0])
-    vt = vcfg(L, intr).init(0.0, frames[0][1], 0.0, frames[0][0])
+    ot = O.Tracker(O.make_config(L, intr, candidates_mode=mode), 0.0, frames[0][1], 0.0, frames[0][0])
+    vt = vcfg(L, intr, mode).init(0.0, frames[0][1], 0.0, frames[0][0])
     switches = 0
     for k in range(1, len(frames)):
         g, d = frames[k]
