@@ -175,8 +175,11 @@ class Tracker:
             raise ValueError("oracle: pyramid shorter than nb_levels (the reference would panic)")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().vo_tracker_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vo_tracker_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def track(self, depth_t, depth, img_t, gray):

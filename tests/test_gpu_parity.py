@@ -109,7 +109,8 @@ def test_lm_eval_operator_vs_golden(path):
 
 # ------------------------------------------------------------------------------------------------ live oracle
 @pytest.mark.parametrize("rows,cols,L,n,mode", [(120, 160, 4, 24, 0), (240, 320, 5, 8, 0), (480, 640, 6, 6, 0),
-                                                 (97, 131, 3, 6, 0), (120, 160, 4, 6, 1), (101, 135, 3, 4, 1), (64, 64, 1, 2, 0)])
+                                                 (97, 131, 3, 6, 0), (120, 160, 4, 6, 1), (101, 135, 3, 4, 1), (64, 64, 1, 2, 0),
+                                                 (384, 512, 8, 3, 0), (384, 512, 8, 2, 1), (200, 328, 7, 3, 0), (66, 130, 2, 3, 1)])
 def test_track_pairs_vs_oracle(rows, cols, L, n, mode):
     intr = O.scaled_intrinsics(rows, cols)
     kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=0x5EED4000 + rows, intr=intr)
