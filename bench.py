@@ -37,8 +37,9 @@ def parse():
     p.add_argument("--pairs", type=int, default=1024,
                    help="frame pairs per GPU per step (weak scaling). 1024 keeps 4 workgroup-waves of pairs per CU in flight; "
                         "SURVEY.md §8d's 256 (one pair per CU) is latency-bound: see DESIGN.md §7")
-    p.add_argument("--candidates", choices=["dense", "c2f"], default="dense",
-                   help="dense = BASELINE configs[1] (extension); c2f = the reference's coarse-to-fine selection")
+    p.add_argument("--candidates", choices=["dense", "c2f", "dso"], default="dense",
+                   help="dense = BASELINE configs[1] (extension); c2f = the reference's coarse-to-fine selection; "
+                        "dso = DSO-style selection (config 3; piecewise-constant synthetic texture)")
     p.add_argument("--rows", type=int, default=480)
     p.add_argument("--cols", type=int, default=640)
     p.add_argument("--levels", type=int, default=6)
@@ -79,9 +80,11 @@ class Workload:
         n, rows, cols, L = args.pairs, args.rows, args.cols, args.levels
         from oracle import oracle as O  # only for the intrinsics helper constants (no compute)
         self.intr = O.scaled_intrinsics(rows, cols)
+        self.mode_id = {"dense": V.CANDIDATES_DENSE, "c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO}[mode]
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(self.intr[:2], self.intr[2:4], self.intr[4]),
-                       candidates_mode=V.CANDIDATES_DENSE if mode == "dense" else V.CANDIDATES_COARSE_TO_FINE,
-                       huber_delta=args.huber)
+                       candidates_mode=self.mode_id, huber_delta=args.huber)
+        if mode == "dso":
+            seed0 |= 1 << 63  # piecewise-constant texture: the DSO thresholds reject the smooth texture entirely
         self.cfg = cfg
         self.batch = V.Batch(cfg, n, rows, cols)
         self.kg, self.kd, self.cg, _, self.gt = V.synth_render_pairs(seed0, n, rows, cols, self.intr, device=device)
@@ -207,7 +210,8 @@ def main():
                          if dense and (args.rows, args.cols, args.levels) == (480, 640, 6) else
                          f"synthetic {args.cols}x{args.rows} gray u8 + depth u16, {args.levels}-level pyramid, {args.candidates} candidates"),
             "pairs_per_gpu": args.pairs,
-            "candidates": "dense (all-true level-0 mask, extension)" if dense else "coarse_to_fine (reference selection)",
+            "candidates": {"dense": "dense (all-true level-0 mask, extension)", "c2f": "coarse_to_fine (reference selection)",
+                           "dso": "DSO-style selection (dso.rs, examples/candidates_dso.rs parameters)"}[args.candidates],
             "huber_delta": args.huber,
             "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of poses per step" if world > 1 else "1 GPU",
             "launch": "hipGraph replay" if args.graph else "eager",
@@ -236,7 +240,7 @@ def main():
 
     if rank == 0 and world == 1:
         # ---- secondary measurement: the other candidate mode (reference selection when the headline is dense)
-        if not args.no_secondary:
+        if not args.no_secondary and args.candidates != "dso":
             other = "c2f" if dense else "dense"
             w2 = Workload(V, args, other, device, seed0)
             w2.batch.enable_kernel_timing(ring)
@@ -263,7 +267,7 @@ def main():
             kg = main_w.kg[:n_cpu].cpu().numpy()
             kd = main_w.kd[:n_cpu].cpu().numpy().view(np.uint16)
             cg = main_w.cg[:n_cpu].cpu().numpy()
-            ocfg = O.make_config(args.levels, main_w.intr, candidates_mode=1 if dense else 0, huber_delta=args.huber)
+            ocfg = O.make_config(args.levels, main_w.intr, candidates_mode=main_w.mode_id, huber_delta=args.huber)
             t0 = time.perf_counter()
             ref = O.track_pairs(ocfg, kg, kd, cg, n_threads=1)
             t_cpu = time.perf_counter() - t0

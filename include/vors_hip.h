@@ -37,8 +37,11 @@ typedef enum vors_status {
 enum { VORS_ROW_MAJOR = 0, VORS_COL_MAJOR = 1 };
 
 /* Candidate mask source. 0 reproduces the reference (candidates::coarse_to_fine, inverse_compositional.rs:120-125).
- * 1 = dense: all-true level-0 mask (extension for BASELINE config "dense candidates"; not in the reference). */
-enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1 };
+ * 1 = dense: all-true level-0 mask (extension for BASELINE config "dense candidates"; not in the reference).
+ * 2 = DSO-style selection (src/core/candidates/dso.rs with the parameters of examples/candidates_dso.rs:40-59) as the
+ *     level-0 mask source (BASELINE config 3; the reference's Tracker never uses it). Its random sub-sampling branch uses a
+ *     counter-based hash instead of the reference's unseeded thread_rng. */
+enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1, VORS_CANDIDATES_DSO = 2 };
 
 /* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
 enum { VORS_TRACK_OK = 0, VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT = 1 };

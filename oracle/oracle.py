@@ -343,6 +343,18 @@ def mean_pyramid(img, max_levels):
     return levels
 
 
+def dso_mask(img, nb_target=2000, seed=0x5EEDD50):
+    """dso::select with the parameters of examples/candidates_dso.rs -> (mask uint8[rows, cols], block sizes of the rounds)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols = img.shape
+    mask = np.zeros((rows, cols), np.uint8)
+    bs = np.zeros(3, np.int32)
+    f = lib().vo_dso_mask
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+    n = f(_u8(img), rows, cols, nb_target, seed, _u8(mask), _i32(bs))
+    return mask, list(bs[:n])
+
+
 def prune_with_thresh(thresh, a, b, c, d):
     out = np.zeros(4, np.uint8)
     lib().vo_prune_with_thresh(thresh, a, b, c, d, _u8(out))

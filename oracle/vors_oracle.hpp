@@ -21,6 +21,7 @@
 #pragma once
 #include <cmath>
 #include <cstddef>
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <utility>
@@ -500,6 +501,187 @@ inline std::vector<DMatrix<uint8_t>> select(uint16_t diff_threshold, const std::
 }  // namespace candidates
 
 // ---------------------------------------------------------------------------------------------
+// src/core/candidates/dso.rs — DSO-style candidate selection. NOT used by the reference's Tracker (which hard-wires
+// coarse_to_fine, inverse_compositional.rs:16,120-125); only by examples/candidates_dso.rs:40-59, whose parameters are
+// used when it serves as an alternative level-0 mask source here (candidates_mode = 2, BASELINE config 3).
+// Deviation: the reference's random sub-sampling branch draws from an UNSEEDED rand::thread_rng() (dso.rs:140-143), which
+// nothing can reproduce; it is replaced by a counter-based hash of (seed, row, col) so that results are repeatable.
+// ---------------------------------------------------------------------------------------------
+namespace gradient {
+// gradient.rs:49-65: ((gx^2 + gy^2) / 4) as u16 with un-halved centred differences; 1-px border = 0.
+inline DMatrix<uint16_t> squared_norm_direct(const DMatrix<uint8_t>& im) {
+    const int nr = im.nrows, nc = im.ncols;
+    DMatrix<uint16_t> out(nr, nc, 0);
+    for (int j = 0; j < nc - 2; ++j)
+        for (int i = 0; i < nr - 2; ++i) {
+            const int32_t gx = (int32_t)im(i + 1, j + 2) - (int32_t)im(i + 1, j);
+            const int32_t gy = (int32_t)im(i + 2, j + 1) - (int32_t)im(i, j + 1);
+            out(i + 1, j + 1) = (uint16_t)((gx * gx + gy * gy) / 4);
+        }
+    return out;
+}
+}  // namespace gradient
+
+namespace dso {
+struct RegionConfig {  // dso.rs:38-43
+    size_t size;
+    Float coef_a;
+    uint16_t coef_b;
+};
+struct BlockConfig {  // dso.rs:46-54
+    size_t base_size, nb_levels;
+    Float threshold_factor;
+};
+struct RecursiveConfig {  // dso.rs:59-70
+    size_t nb_iterations_left;
+    Float low_thresh, high_thresh, random_thresh;
+};
+struct MaxGrad {
+    uint16_t g;
+    size_t i, j;
+};
+inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// dso.rs:307-325
+inline DMatrix<uint16_t> region_median_gradients(const DMatrix<uint16_t>& g, size_t size) {
+    const size_t nr = g.nrows, nc = g.ncols;
+    const size_t rr = nr / size + (nr % size ? 1 : 0), rc = nc / size + (nc % size ? 1 : 0);
+    DMatrix<uint16_t> out((int)rr, (int)rc, 0);
+    std::vector<uint16_t> tmp;
+    for (size_t j = 0; j < rc; ++j)
+        for (size_t i = 0; i < rr; ++i) {
+            const size_t h = std::min(size, nr - i * size), w = std::min(size, nc - j * size);
+            tmp.clear();
+            for (size_t c = 0; c < w; ++c)
+                for (size_t r = 0; r < h; ++r) tmp.push_back(g((int)(i * size + r), (int)(j * size + c)));
+            std::sort(tmp.begin(), tmp.end());
+            out((int)i, (int)j) = tmp[tmp.size() / 2];
+        }
+    return out;
+}
+// dso.rs:284-303: threshold = a * (mean3x3(median) + b)^2, cast to u16 (truncation)
+inline DMatrix<uint16_t> region_thresholds(const DMatrix<uint16_t>& med, Float a, uint16_t b) {
+    const int nr = med.nrows, nc = med.ncols;
+    DMatrix<uint16_t> out(nr, nc, 0);
+    for (int j = 0; j < nc; ++j)
+        for (int i = 0; i < nr; ++i) {
+            const int si = std::max(0, i - 1), sj = std::max(0, j - 1), ei = std::min(nr, i + 2), ej = std::min(nc, j + 2);
+            uint16_t sum = 0;
+            int n = 0;
+            for (int jj = sj; jj < ej; ++jj)
+                for (int ii = si; ii < ei; ++ii) {
+                    sum = (uint16_t)(sum + med(ii, jj));
+                    ++n;
+                }
+            const Float t = (Float)sum / (Float)n + (Float)b;
+            out(i, j) = (uint16_t)(a * t * t);
+        }
+    return out;
+}
+// dso.rs:192-222: first maximum in column-major order inside each block
+inline DMatrix<MaxGrad> init_max_gradients(const DMatrix<uint16_t>& g, size_t bs) {
+    const size_t nr = g.nrows, nc = g.ncols;
+    const size_t br = nr / bs + (nr % bs ? 1 : 0), bc = nc / bs + (nc % bs ? 1 : 0);
+    DMatrix<MaxGrad> out((int)br, (int)bc, MaxGrad{0, 0, 0});
+    for (size_t bj = 0; bj < bc; ++bj)
+        for (size_t bi = 0; bi < br; ++bi) {
+            const size_t si = bi * bs, sj = bj * bs, ei = std::min(si + bs, nr), ej = std::min(sj + bs, nc);
+            MaxGrad m{g((int)si, (int)sj), si, sj};
+            for (size_t j = sj; j < ej; ++j)
+                for (size_t i = si; i < ei; ++i)
+                    if (g((int)i, (int)j) > m.g) m = MaxGrad{g((int)i, (int)j), i, j};
+            out((int)bi, (int)bj) = m;
+        }
+    return out;
+}
+// dso.rs:225-241: g_max(g1, g_max(g2, g_max(g3, g4))), ties keep the first argument
+inline MaxGrad max_of_four(const MaxGrad& g1, const MaxGrad& g2, const MaxGrad& g3, const MaxGrad& g4) {
+    auto gmax = [](const MaxGrad& a, const MaxGrad& b) { return a.g < b.g ? b : a; };
+    return gmax(g1, gmax(g2, gmax(g3, g4)));
+}
+// dso.rs:156-189 + 248-276. Returns the per-level pick counts; `picked` = 0 or the level (1-based) that picked the pixel.
+inline std::vector<size_t> pick_all_block_candidates(const BlockConfig& bc, size_t regions_size, const DMatrix<uint16_t>& thr,
+                                                     const DMatrix<uint16_t>& g, DMatrix<uint8_t>& picked) {
+    auto multires = limited_sequence(bc.nb_levels, init_max_gradients(g, bc.base_size), [](const DMatrix<MaxGrad>& m, DMatrix<MaxGrad>& o) {
+        return halve<MaxGrad, MaxGrad>(m, max_of_four, o);
+    });
+    Float coef = 1.0f;
+    std::vector<size_t> nb_picked;
+    DMatrix<uint8_t> mask(multires[0].nrows, multires[0].ncols, (uint8_t)1);
+    picked = DMatrix<uint8_t>(g.nrows, g.ncols, (uint8_t)0);
+    for (size_t level = 0; level < multires.size(); ++level) {
+        const DMatrix<MaxGrad>& mg = multires[level];
+        const int mh = mask.nrows, mw = mask.ncols;
+        DMatrix<uint8_t> next(mh / 2, mw / 2, (uint8_t)1);
+        size_t n = 0;
+        for (int j = 0; j < mw / 2 * 2; ++j)
+            for (int i = 0; i < mh / 2 * 2; ++i) {
+                if (mask(i, j)) {
+                    const MaxGrad& m = mg(i, j);
+                    const uint16_t threshold = thr((int)(m.i / regions_size), (int)(m.j / regions_size));
+                    if ((Float)m.g >= coef * (Float)threshold) {
+                        next(i / 2, j / 2) = 0;
+                        picked((int)m.i, (int)m.j) = (uint8_t)(level + 1);
+                        ++n;
+                    }
+                } else {
+                    next(i / 2, j / 2) = 0;
+                }
+            }
+        nb_picked.push_back(n);
+        mask = std::move(next);
+        coef *= bc.threshold_factor;
+    }
+    return nb_picked;
+}
+// dso.rs:98-147
+inline DMatrix<uint8_t> select(const DMatrix<uint16_t>& g, const RegionConfig& rc, BlockConfig bc, RecursiveConfig rec, size_t nb_target,
+                               uint64_t seed, std::vector<size_t>* trace_base_sizes = nullptr) {
+    const DMatrix<uint16_t> med = region_median_gradients(g, rc.size);
+    const DMatrix<uint16_t> thr = region_thresholds(med, rc.coef_a, rc.coef_b);
+    for (;;) {
+        if (trace_base_sizes) trace_base_sizes->push_back(bc.base_size);
+        DMatrix<uint8_t> picked;
+        const std::vector<size_t> counts = pick_all_block_candidates(bc, rc.size, thr, g, picked);
+        size_t nb_candidates = 0;
+        for (size_t c : counts) nb_candidates += c;
+        const Float ratio = (Float)nb_candidates / (Float)nb_target;
+        const Float ts = std::sqrt(ratio) * ((Float)bc.base_size + 1.0f) - 1.0f;
+        const size_t target_size = (size_t)std::max(1, (int)std::round(ts));
+        DMatrix<uint8_t> mask(picked.nrows, picked.ncols, (uint8_t)0);
+        if (ratio < rec.low_thresh || ratio > rec.high_thresh) {
+            if (target_size != bc.base_size && rec.nb_iterations_left > 0) {
+                bc.base_size = target_size;
+                rec.nb_iterations_left -= 1;
+                continue;  // the medians / thresholds of the recursive call are identical
+            }
+            for (size_t k = 0; k < mask.data.size(); ++k) mask.data[k] = picked.data[k] > 0;
+        } else if (ratio > rec.random_thresh) {
+            const uint8_t keep = (uint8_t)(255.0f / ratio);
+            for (int j = 0; j < mask.ncols; ++j)
+                for (int i = 0; i < mask.nrows; ++i) {
+                    const uint8_t r = (uint8_t)(splitmix64(seed ^ splitmix64(((uint64_t)(uint32_t)i << 32) | (uint32_t)j)) & 0xff);
+                    mask(i, j) = picked(i, j) > 0 && r <= keep;  // deviation: counter-based stand-in for rng.gen::<u8>()
+                }
+        } else {
+            for (size_t k = 0; k < mask.data.size(); ++k) mask.data[k] = picked.data[k] > 0;
+        }
+        return mask;
+    }
+}
+// examples/candidates_dso.rs:40-59: gradient magnitude = sqrt(squared_norm_direct) as u16; defaults with 2 recursion rounds.
+inline DMatrix<uint8_t> select_like_example(const DMatrix<uint8_t>& img, size_t nb_target, uint64_t seed, std::vector<size_t>* trace = nullptr) {
+    DMatrix<uint16_t> g = gradient::squared_norm_direct(img);
+    for (auto& v : g.data) v = (uint16_t)std::sqrt((Float)v);
+    return select(g, RegionConfig{32, 1.0f, 3}, BlockConfig{4, 3, 0.5f}, RecursiveConfig{2, 0.8f, 4.0f, 1.1f}, nb_target, seed, trace);
+}
+}  // namespace dso
+
+// ---------------------------------------------------------------------------------------------
 // src/core/inverse_depth.rs
 // ---------------------------------------------------------------------------------------------
 struct InverseDepth {  // inverse_depth.rs:12-19
@@ -754,7 +936,9 @@ namespace track {
 
 // Candidate-mask source. 0 = candidates::coarse_to_fine (the reference, inverse_compositional.rs:120-125).
 // 1 = dense all-true level-0 mask (build extension for BASELINE config 2; SURVEY.md top table).
-enum CandidatesMode : int { COARSE_TO_FINE = 0, DENSE = 1 };
+enum CandidatesMode : int { COARSE_TO_FINE = 0, DENSE = 1, DSO = 2 };
+constexpr size_t DSO_NB_TARGET = 2000;      // examples/candidates_dso.rs:58
+constexpr uint64_t DSO_SEED = 0x5EEDD50ull;  // counter-RNG seed of the sub-sampling branch (deviation, see namespace dso)
 
 struct Config {  // inverse_compositional.rs:37-49
     size_t nb_levels;
@@ -853,6 +1037,8 @@ inline MultiresData precompute_multires_data(const Config& config, const DMatrix
     DMatrix<uint8_t> candidates_points;
     if (config.candidates_mode == DENSE) {
         candidates_points = DMatrix<uint8_t>(img_multires[0].nrows, img_multires[0].ncols, (uint8_t)1);
+    } else if (config.candidates_mode == DSO) {
+        candidates_points = dso::select_like_example(img_multires[0], DSO_NB_TARGET, DSO_SEED);
     } else {
         auto masks = candidates::select(config.candidates_diff_threshold, g2);
         candidates_points = std::move(masks.back());  // .pop().unwrap()

@@ -276,6 +276,16 @@ int vo_mean_pyramid(const uint8_t* img, int rows, int cols, int max_levels, uint
     }
     return (int)pyr.size();
 }
+// DSO-style level-0 mask (candidates/dso.rs with the parameters of examples/candidates_dso.rs). base_sizes (nullable, >= 3
+// entries): the block sizes of the successive rounds; returns the number of rounds.
+int vo_dso_mask(const uint8_t* img, int rows, int cols, int nb_target, uint64_t seed, uint8_t* mask_out, int32_t* base_sizes) {
+    std::vector<size_t> trace;
+    const auto m = dso::select_like_example(DMatrix<uint8_t>::from_row_slice(rows, cols, img), (size_t)nb_target, seed, &trace);
+    m.to_row_slice(mask_out);
+    if (base_sizes)
+        for (size_t k = 0; k < trace.size() && k < 3; ++k) base_sizes[k] = (int32_t)trace[k];
+    return (int)trace.size();
+}
 void vo_prune_with_thresh(int thresh, int a, int b, int c, int d, uint8_t out[4]) {
     bool r[4];
     candidates::prune_with_thresh((uint16_t)thresh, (uint16_t)a, (uint16_t)b, (uint16_t)c, (uint16_t)d, r);

@@ -394,3 +394,37 @@ def test_batch_keyframe_reuse_and_stream_capture():
         graph.replay()
         torch.cuda.synchronize()
         assert (bits(poses.cpu().numpy()) == bits(expect.cpu().numpy())).all()
+
+
+BLOCKY = 1 << 63  # seeds with the top bit set render the piecewise-constant texture (synth_scene.h)
+
+
+@pytest.mark.parametrize("rows,cols,L,n", [(480, 640, 6, 4), (240, 320, 5, 3), (250, 331, 4, 2), (120, 160, 4, 3), (60, 80, 3, 2)])
+def test_dso_candidates_vs_oracle(rows, cols, L, n):
+    """candidates_mode = 2: DSO-style selection (dso.rs + examples/candidates_dso.rs parameters) as the level-0 mask source.
+    The smaller sizes push the candidate ratio outside [0.8, 4] (recursive rounds with an adapted block size) or into
+    (1.1, 4] (hash-based sub-sampling branch). Masks and candidates are bit-exact against the oracle; poses within tolerance."""
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=BLOCKY | 0x5EEDE000, intr=intr)
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=2), kg, kd, cg)
+    b, poses, status, stats, _ = run_batch(vcfg(L, intr, 2), kg, kd, cg)
+    rounds = []
+    for p in range(n):
+        omask, bs = O.dso_mask(kg[p])
+        rounds.append(bs)
+        xy, iz, jac, tm = b.points(p, 0)
+        mask = np.zeros((rows, cols), np.uint8)
+        mask[xy[:, 1], xy[:, 0]] = 1
+        assert (mask == (omask & (kd[p] != 0))).all(), f"DSO mask of pair {p} (rounds {bs})"
+    tr = O.Tracker(O.make_config(L, intr, candidates_mode=2), 0.0, kd[0], 0.0, kg[0])
+    for l in range(L):
+        xy, iz, jac, tm = b.points(0, l)
+        oxy, oiz, ojac = tr.points(l)
+        o1, o2 = sort_xy(xy), sort_xy(oxy)
+        assert xy.shape == oxy.shape and (xy[o1] == oxy[o2]).all(), f"level {l}"
+        assert (bits(iz[o1]) == bits(oiz[o2])).all() and (bits(jac[o1]) == bits(ojac[o2])).all(), f"level {l}"
+    print(f"[{cols}x{rows}] DSO rounds (block sizes) {rounds}; level-0 points {stats['n_points'][:, 0]}")
+    assert (stats["n_points"][:, :L] == ref["n_points"]).all()
+    assert (status == ref["status"]).all()
+    ok = status == 0
+    assert np.abs(poses[ok] - ref["poses"][ok]).max(initial=0) < POSE_TOL

@@ -181,3 +181,21 @@ def test_oracle_pyramid_too_short_is_an_error():
     kg, kd, _, _, _ = O.synth_pair(1, 16, 16)
     with pytest.raises(ValueError):
         O.Tracker(O.make_config(6, O.scaled_intrinsics(16, 16)), 0.0, kd, 0.0, kg)
+
+
+def test_dso_selector_structure():
+    """dso::select (examples/candidates_dso.rs parameters) on a piecewise-constant scene: about the target number of points,
+    every pick is a block maximum, recursion / sub-sampling branches are reachable, and the result is repeatable."""
+    B = 1 << 63
+    kg, kd, cg, cd, gt = O.synth_pair(B | 11, 480, 640)
+    m, rounds = O.dso_mask(kg)
+    assert 1600 <= m.sum() <= 2400 and rounds == [4]
+    m2, _ = O.dso_mask(kg)
+    assert (m == m2).all()
+    # at most one pick per 4x4 block (base size 4, level 1) and none on the 1-px border (gradient magnitude is 0 there)
+    assert m.reshape(120, 4, 160, 4).sum(axis=(1, 3)).max() == 1
+    assert m[0].sum() == 0 and m[-1].sum() == 0 and m[:, 0].sum() == 0 and m[:, -1].sum() == 0
+    small = O.synth_pair(B | 12, 120, 160, O.scaled_intrinsics(120, 160))[0]
+    assert O.dso_mask(small)[1][:2] == [4, 2]                      # too few candidates -> smaller blocks, second round
+    # the smooth texture has large gradient MAGNITUDES everywhere: squared-median thresholds reject everything (as the reference would)
+    assert O.dso_mask(O.synth_pair(13, 240, 320)[0])[0].sum() == 0

@@ -48,7 +48,8 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     if (cfg->nb_levels < 1 || cfg->nb_levels > VORS_MAX_LEVELS)
         return fail(VORS_ERR_INVALID_ARGUMENT, "nb_levels must be in [1, " + std::to_string(VORS_MAX_LEVELS) + "]");
     if (rows < 2 || cols < 2 || rows > 65535 || cols > 65535) return fail(VORS_ERR_INVALID_ARGUMENT, "rows/cols must be in [2, 65535]");
-    if (cfg->candidates_mode != VORS_CANDIDATES_COARSE_TO_FINE && cfg->candidates_mode != VORS_CANDIDATES_DENSE)
+    if (cfg->candidates_mode != VORS_CANDIDATES_COARSE_TO_FINE && cfg->candidates_mode != VORS_CANDIDATES_DENSE &&
+        cfg->candidates_mode != VORS_CANDIDATES_DSO)
         return fail(VORS_ERR_INVALID_ARGUMENT, "unknown candidates_mode");
     if (cfg->candidates_diff_threshold < 0 || cfg->candidates_diff_threshold > 65535)
         return fail(VORS_ERR_INVALID_ARGUMENT, "candidates_diff_threshold must fit u16");
@@ -88,8 +89,12 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     const long n_roots = (long)g->root_rows * g->root_cols;
     long slot_off = 0;
     const bool dense = g->mode == VORS_CANDIDATES_DENSE;
+    const bool generic = g->mode == VORS_CANDIDATES_DSO;
     for (int l = 0; l < g->L; ++l) {
         long n = dense ? (long)g->lv[l].rows * g->lv[l].cols : n_roots * (1L << (g->L - 1 - l));
+        // generic-mask modes: compacted candidate lists with a fixed capacity per level (the DSO selector aims at 2000 points
+        // and re-runs when it gets more than 4x that; 65536 leaves a wide margin, excess candidates would be dropped)
+        if (generic) n = std::min((long)g->lv[l].rows * g->lv[l].cols, 65536L);
         if (slot_off + n > 0x7fffffffL) return fail(VORS_ERR_UNSUPPORTED, "too many candidate slots");
         g->lv[l].n_slots = (int)n;
         if (dense && l == 0) {  // dense level 0 stores nothing per point (recomputed on the fly by the LM kernel)
@@ -118,6 +123,10 @@ struct vors_batch {
     Records rec{};
     uint64_t bytes = 0;
     int lm_block = 256;  // threads per frame pair in the LM kernel (256 / 512 / 1024)
+    // generic-mask (DSO) mode workspaces
+    DsoWs dso{};
+    PixelPlanes pp{};
+    uint8_t* mask0 = nullptr;
     // Per-stage HIP-event ring (stage: 0 keyframe pyramid, 1 keyframe precompute, 2 current pyramid, 3 LM kernel).
     // Events are only RECORDED on the caller's stream during a step (non-blocking); elapsed times are read afterwards.
     int ring = 0;
@@ -143,6 +152,10 @@ static void batch_free(vors_batch* b) {
     if (b->rec.IZ) (void)hipFree(b->rec.IZ);
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
+    void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
+                     b->mask0, b->pp.iz, b->pp.v};
+    for (void* p : extra)
+        if (p) (void)hipFree(p);
     for (int st = 0; st < 4; ++st) {
         for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
         for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
@@ -215,6 +228,29 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->rec.C, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
+    }
+    if (e == hipSuccess && g.mode == VORS_CANDIDATES_DSO) {
+        const int rr = (rows + 31) / 32, rc = (cols + 31) / 32;
+        b->dso.n_regions = rr * rc;
+        b->dso.max_stride = g.S0 + g.S0 / 4 + g.S0 / 16 + 64;  // worst case: base block size 1
+        b->dso.mask_stride = g.S0 + g.S0 / 4 + g.S0 / 16 + 64;
+        int off = 0;
+        for (int l = 0; l < g.L; ++l) {
+            b->pp.off[l] = off;
+            off += (g.lv[l].rows * g.lv[l].cols + 3) & ~3;
+        }
+        b->pp.stride = off;
+        if (e == hipSuccess) e = dmalloc(&b->dso.gmag, np * g.S0, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.median, np * b->dso.n_regions, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.thresh, np * b->dso.n_regions, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.max_g, np * b->dso.max_stride, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.max_pos, np * b->dso.max_stride, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.mask1, np * b->dso.mask_stride, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.picked, np * g.S0, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->dso.state, np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->mask0, np * g.S0, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->pp.iz, np * b->pp.stride, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {
@@ -289,7 +325,12 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     launch_pyramid(b->g, kf, n_pairs, s);
     STAGE_END(b, 0, s);
     STAGE_BEGIN(b, 1, s);
-    launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
+    if (b->g.mode == VORS_CANDIDATES_DSO) {
+        launch_dso_mask(b->g, kf, b->dso, b->mask0, n_pairs, s);
+        launch_keyframe_generic(b->g, kf, d_kf_depth, b->mask0, b->pp, b->rec, n_pairs, s);
+    } else {
+        launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
+    }
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -303,7 +344,12 @@ static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint1
     b->kf_depth = d_depth;
     Pyramid kf{b->kf_level0, b->kf_upper};
     STAGE_BEGIN(b, 1, s);
-    launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
+    if (b->g.mode == VORS_CANDIDATES_DSO) {
+        launch_dso_mask(b->g, kf, b->dso, b->mask0, n_pairs, s);
+        launch_keyframe_generic(b->g, kf, d_depth, b->mask0, b->pp, b->rec, n_pairs, s);
+    } else {
+        launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
+    }
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;

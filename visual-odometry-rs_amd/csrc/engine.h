@@ -46,6 +46,29 @@ struct Records {
     const float2* LUT;  // dense mode only: depth u16 -> (scale / depth, 1 / (scale / depth)), exact
 };
 
+// Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
+struct DsoState {
+    int base_size, iterations_left, done, random_keep, count;
+};
+struct DsoWs {
+    uint8_t* gmag;      // [S0] gradient magnitude (<= 180)
+    uint16_t* median;   // [n_regions]
+    uint16_t* thresh;   // [n_regions]
+    uint8_t* max_g;     // [max_stride] block maxima of the 3 levels, concatenated
+    uint32_t* max_pos;  // [max_stride] their pixel positions (row * cols + col)
+    uint8_t* mask1;     // [mask_stride] block masks of levels 1 and 2 (+ the discarded mask after the last level)
+    uint8_t* picked;    // [S0] 0 or the level (1-based) that picked the pixel
+    DsoState* state;    // [1]
+    int n_regions, max_stride, mask_stride;
+};
+// Per-pixel inverse-depth planes of the generic-mask keyframe path (all levels).
+struct PixelPlanes {
+    float* iz;  // NaN = Unknown
+    float* v;   // < 0 = Unknown
+    int off[VORS_MAX_LEVELS];
+    int stride;
+};
+
 // Image pyramid of a batch: level 0 is the caller's buffer (zero copy), levels >= 1 live in `upper`.
 struct Pyramid {
     const uint8_t* level0;  // pair stride S0
@@ -56,6 +79,9 @@ void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int
 void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
+void launch_dso_mask(const Geom& g, Pyramid kf, DsoWs ws, uint8_t* mask_out, int n_pairs, hipStream_t s);
+void launch_keyframe_generic(const Geom& g, Pyramid kf, const uint16_t* depth, const uint8_t* mask, PixelPlanes pp, Records rec,
+                             int n_pairs, hipStream_t s);
 void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
                               hipStream_t s);
 // `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).

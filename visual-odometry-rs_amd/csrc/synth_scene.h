@@ -47,11 +47,19 @@ VORS_HD double value_noise(uint64_t seed, double p, double q) {
     return (1 - b) * ((1 - a) * v00 + a * v10) + b * ((1 - a) * v01 + a * v11);
 }
 // Plane texture in metres on the plane (p, q) -> grey level (not yet clamped).
+// Seeds with the top bit set select a PIECEWISE-CONSTANT texture (12 cm cells of random grey, plus a faint shading): mostly
+// flat regions separated by strong edges, the kind of image the DSO-style selector (median-based thresholds) is made for.
 VORS_HD double texture(uint64_t seed, double p, double q) {
     const double two_pi = 6.283185307179586476925;
+    if (seed >> 63) {
+        const double cell = 0.12;
+        const int64_t ix = (int64_t)floor(p / cell), iy = (int64_t)floor(q / cell);
+        return 128.0 + 100.0 * lattice(seed, ix, iy) + 3.0 * sin(two_pi * 0.4 * (p - q));
+    }
     return 128.0 + 50.0 * sin(two_pi * 3.1 * p) + 40.0 * sin(two_pi * 7.3 * q + 1.3) +
            25.0 * sin(two_pi * 0.6 * (p + q) + 0.4) + 30.0 * value_noise(seed, p / 0.08, q / 0.08);
 }
+constexpr uint64_t BLOCKY = 1ull << 63;
 
 // exp of a twist xi = (v, w) in double: X_cam = R X + t.
 VORS_HD RigidD se3_exp_d(const double xi[6]) {

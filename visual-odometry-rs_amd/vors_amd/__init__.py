@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libvors_hip.so")
 MAX_LEVELS = 8
 
 ROW_MAJOR, COL_MAJOR = 0, 1
-CANDIDATES_COARSE_TO_FINE, CANDIDATES_DENSE = 0, 1
+CANDIDATES_COARSE_TO_FINE, CANDIDATES_DENSE, CANDIDATES_DSO = 0, 1, 2
 TRACK_OK, TRACK_OPTIMIZER_FAILED_POSE_KEPT = 0, 1
 
 
