@@ -743,7 +743,17 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
             if constexpr (DENSE) {
                 if (lvl == 0) {
                     const uint16_t* d = kf_depth + (size_t)pair * g.S0;
-                    for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (d[i] != 0) ? 1.0f : 0.f;
+                    if ((g.S0 & 7) == 0) {  // 8 depth values per 16-byte load
+                        const uint4* d8 = reinterpret_cast<const uint4*>(d);
+                        for (int i = threadIdx.x; i < lg.n_slots / 8; i += BLOCK) {
+                            const uint4 w = d8[i];
+                            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) n += ((ww[k] & 0xffffu) ? 1.0f : 0.f) + ((ww[k] >> 16) ? 1.0f : 0.f);
+                        }
+                    } else {
+                        for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (d[i] != 0) ? 1.0f : 0.f;
+                    }
                 } else {
                     const float* z = rec.IZ + (size_t)pair * g.slots_total + lg.slot_off;
                     for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) {
