@@ -428,3 +428,27 @@ def test_dso_candidates_vs_oracle(rows, cols, L, n):
     assert (status == ref["status"]).all()
     ok = status == 0
     assert np.abs(poses[ok] - ref["poses"][ok]).max(initial=0) < POSE_TOL
+
+
+def test_dense_with_unaligned_device_buffers():
+    """Device buffers that are not 16-byte aligned must fall back from the wide-load quad source to the per-pixel source and
+    give the same poses."""
+    import torch
+    rows, cols, L, n = 120, 160, 4, 3
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=0x5EEDF000, intr=intr)
+    cfg = vcfg(L, intr, 1)
+    _, p_aligned, s_aligned, _, _ = run_batch(cfg, kg, kd, cg)
+    S = rows * cols
+    raw_g = torch.zeros(n * S + 3, dtype=torch.uint8, device="cuda")
+    raw_c = torch.zeros(n * S + 3, dtype=torch.uint8, device="cuda")
+    raw_d = torch.zeros(n * S + 1, dtype=torch.int16, device="cuda")
+    t_kg = raw_g[3:].view(n, rows, cols); t_cg = raw_c[3:].view(n, rows, cols); t_kd = raw_d[1:].view(n, rows, cols)
+    t_kg.copy_(torch.from_numpy(kg)); t_cg.copy_(torch.from_numpy(cg)); t_kd.copy_(torch.from_numpy(kd.view(np.int16)))
+    assert t_kg.data_ptr() % 16 != 0 and t_kd.data_ptr() % 16 != 0
+    b = V.Batch(cfg, n, rows, cols)
+    poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    b.track_pairs(t_kg, t_kd, t_cg, poses, status)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == s_aligned).all()
+    assert np.abs(poses.cpu().numpy() - p_aligned).max() < 1e-5

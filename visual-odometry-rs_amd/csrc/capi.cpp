@@ -275,7 +275,10 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
             b->g.lv[l].fv = FastDiv{fv, 1.0f / fv, (ok_v && pow2_v) ? 1 : 0};
         }
     }
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) {
+        batch_free(b);
+        return fail(VORS_ERR_HIP, "device error while initialising the batch handle");
+    }
     *out = b;
     return VORS_OK;
 }

@@ -28,6 +28,7 @@ struct Geom {
     int upper_stride;   // bytes per pair of levels 1..L-1
     int slots_total;    // record slots per pair (all levels)
     int root_rows, root_cols;  // shape of the coarsest level (= roots of the selection quad-trees)
+    int wide_loads_ok;  // set per launch: the caller's buffers are 16-byte aligned, so the dense quad source may use wide loads
     LevelGeom lv[VORS_MAX_LEVELS];
 };
 

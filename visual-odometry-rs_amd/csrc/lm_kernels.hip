@@ -598,7 +598,7 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
         const float* iz = lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr;
         const int fcols = lvl > 0 ? g.lv[lvl - 1].cols : 0;
         // quads need 4-byte aligned rows in every plane they read (and 16-byte aligned inverse-depth rows)
-        const bool quad_ok = QUADS && (lg.cols % 4 == 0) && (lvl == 0 ? (g.S0 % 4 == 0) : (fcols % 8 == 0));
+        const bool quad_ok = QUADS && g.wide_loads_ok && (lg.cols % 4 == 0) && (lvl == 0 ? (g.S0 % 4 == 0) : (fcols % 8 == 0));
         if (lvl == 0) {
             if constexpr (QUADS) {
                 if (quad_ok) {
@@ -789,9 +789,11 @@ static void launch_lm_track_block(const Geom& g, Pyramid cur, Pyramid kf, const 
                            kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats);
 }
 
-void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                      const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
                      hipStream_t s) {
+    Geom g = g_in;
+    g.wide_loads_ok = (((uintptr_t)kf.level0 | (uintptr_t)kf.upper | (uintptr_t)kf_depth | (uintptr_t)rec.IZ) % 16 == 0) ? 1 : 0;
 #define VORS_LM_ARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, s
     if (g.mode == VORS_CANDIDATES_DENSE) {
         if (block >= 1024) launch_lm_track_block<1024, true>(VORS_LM_ARGS);
