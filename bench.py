@@ -34,9 +34,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--pairs", type=int, default=1024,
-                   help="frame pairs per GPU per step (weak scaling). 1024 keeps 4 workgroup-waves of pairs per CU in flight; "
-                        "SURVEY.md §8d's 256 (one pair per CU) is latency-bound: see DESIGN.md §7")
+    p.add_argument("--pairs", type=int, default=4096,
+                   help="frame pairs per GPU per step (weak scaling; BASELINE config 4's batch size). Pairs need different numbers "
+                        "of LM evaluations, so throughput grows with the batch until the workgroups balance (dense: 80 k pairs/s "
+                        "at 256, 105 k at 1024, 140 k at 4096); SURVEY.md §8d's 256 = one pair per CU. See DESIGN.md §3/§7")
     p.add_argument("--candidates", choices=["dense", "c2f", "dso"], default="dense",
                    help="dense = BASELINE configs[1] (extension); c2f = the reference's coarse-to-fine selection; "
                         "dso = DSO-style selection (config 3; piecewise-constant synthetic texture)")
