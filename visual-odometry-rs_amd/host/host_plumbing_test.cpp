@@ -1,5 +1,6 @@
 // CPU-only self-test of the TUM plumbing (no GPU, no libvors_hip call): parser grammar, Rust float Display, PNG round trips.
 #include <cassert>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -37,6 +38,20 @@ int main(int argc, char** argv) {
     CHECK(!tum_rgbd::parse::associations("1.0 a 2.0\n", a, err));                                                // missing field
     CHECK(tum_rgbd::parse::associations("", a, err) && a.empty());
     CHECK(tum_rgbd::parse::associations("1e3 a -2.5E-1 b", a, err) && a.size() == 1 && a[0].depth_timestamp == 1000.0 && a[0].color_timestamp == -0.25);
+    // ---- trajectory grammar (examples/README.md:41-45 of the reference)
+    {
+        std::vector<tum_rgbd::Frame> fr;
+        CHECK(tum_rgbd::parse::trajectory("# ground truth trajectory\n# timestamp tx ty tz qx qy qz qw\n"
+                                          "1305031098.6659 1.3563 0.6305 1.6380 0.6132 0.5962 -0.3311 -0.3986\n", fr, err));
+        CHECK(fr.size() == 1 && fr[0].timestamp == 1305031098.6659 && fr[0].pose[0] == 1.3563f);
+        const float n2 = fr[0].pose[3] * fr[0].pose[3] + fr[0].pose[4] * fr[0].pose[4] + fr[0].pose[5] * fr[0].pose[5] + fr[0].pose[6] * fr[0].pose[6];
+        CHECK(std::fabs(n2 - 1.0f) < 1e-6f);  // rotation normalised like UnitQuaternion::from_quaternion
+        CHECK(!tum_rgbd::parse::trajectory("1.0 0 0 0 0 0 0\n", fr, err));  // 7 numbers instead of 8
+        // write -> parse round trip of a trajectory line
+        const tum_rgbd::Frame f0{2.5, {0.1f, -0.2f, 0.3f, 0.0f, 0.0f, 0.6f, 0.8f}};
+        CHECK(tum_rgbd::parse::trajectory(tum_rgbd::to_string(f0) + "\n", fr, err) && fr.size() == 1);
+        for (int k = 0; k < 7; ++k) CHECK(std::fabs(fr[0].pose[k] - f0.pose[k]) < 1e-6f);
+    }
     // ---- PNG round trips
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
     const uint32_t w = 37, h = 23;

@@ -118,6 +118,48 @@ inline bool associations(const std::string& content, std::vector<Association>& o
     }
     return true;
 }
+// Trajectory line: comment or `timestamp tx ty tz qx qy qz qw` (tum_rgbd.rs:141-194). The rotation goes through
+// UnitQuaternion::from_quaternion, i.e. it is normalised (tum_rgbd.rs:191).
+inline bool parse_float(const std::string& s, size_t& p, float& out) {
+    double d;
+    if (!parse_double(s, p, d)) return false;
+    out = (float)d;
+    return true;
+}
+inline bool trajectory_line(const std::string& line, std::optional<Frame>& out) {
+    out.reset();
+    if (!line.empty() && line[0] == '#') return true;
+    Frame f;
+    size_t p = 0;
+    float v[7];
+    if (!parse_double(line, p, f.timestamp)) return false;
+    for (int k = 0; k < 7; ++k)
+        if (!parse_space(line, p) || !parse_float(line, p, v[k])) return false;
+    // nalgebra: q / sqrt(norm_squared), 4-vector dot special case (a + c) + (b + d)
+    const float a = v[3] * v[3] + v[5] * v[5], b = v[4] * v[4] + v[6] * v[6];
+    const float n = std::sqrt(a + b);
+    f.pose = Iso3{v[0], v[1], v[2], v[3] / n, v[4] / n, v[5] / n, v[6] / n};
+    out = f;
+    return true;
+}
+// tum_rgbd.rs:102-105
+inline bool trajectory(const std::string& content, std::vector<Frame>& out, std::string& err) {
+    out.clear();
+    size_t pos = 0;
+    while (pos < content.size()) {
+        size_t nl = content.find('\n', pos);
+        std::string line = content.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+        pos = (nl == std::string::npos) ? content.size() : nl + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::optional<Frame> f;
+        if (!trajectory_line(line, f)) {
+            err = "Parsing error";
+            return false;
+        }
+        if (f) out.push_back(*f);
+    }
+    return true;
+}
 }  // namespace parse
 
 }  // namespace tum_rgbd
