@@ -153,7 +153,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
-                     b->mask0, b->pp.iz, b->pp.v};
+                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts};
     for (void* p : extra)
         if (p) (void)hipFree(p);
     for (int st = 0; st < 4; ++st) {
@@ -235,11 +235,17 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         b->dso.max_stride = g.S0 + g.S0 / 4 + g.S0 / 16 + 64;  // worst case: base block size 1
         b->dso.mask_stride = g.S0 + g.S0 / 4 + g.S0 / 16 + 64;
         int off = 0;
-        for (int l = 0; l < g.L; ++l) {
+        for (int l = 0; l < g.L; ++l) {  // level 0 is not stored (mask + depth are read instead)
             b->pp.off[l] = off;
-            off += (g.lv[l].rows * g.lv[l].cols + 3) & ~3;
+            if (l >= 1) off += (g.lv[l].rows * g.lv[l].cols + 3) & ~3;
         }
-        b->pp.stride = off;
+        b->pp.stride = off > 0 ? off : 4;
+        int coff = 0;
+        for (int l = 0; l < g.L; ++l) {
+            b->pp.chunk_off[l] = coff;
+            coff += (g.lv[l].rows * g.lv[l].cols + VORS_CHUNK_PX - 1) / VORS_CHUNK_PX;
+        }
+        b->pp.chunk_off[g.L] = b->pp.chunks_total = coff;
         if (e == hipSuccess) e = dmalloc(&b->dso.gmag, np * g.S0, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.median, np * b->dso.n_regions, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.thresh, np * b->dso.n_regions, &b->bytes);
@@ -251,6 +257,7 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->mask0, np * g.S0, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.iz, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->pp.counts, np * b->pp.chunks_total, &b->bytes);
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {

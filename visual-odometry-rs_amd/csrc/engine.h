@@ -49,7 +49,7 @@ struct Records {
 
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
 struct DsoState {
-    int base_size, iterations_left, done, random_keep, count;
+    int base_size, iterations_left, done, random_keep, count, final_round;
 };
 struct DsoWs {
     uint8_t* gmag;      // [S0] gradient magnitude (<= 180)
@@ -58,7 +58,7 @@ struct DsoWs {
     uint8_t* max_g;     // [max_stride] block maxima of the 3 levels, concatenated
     uint32_t* max_pos;  // [max_stride] their pixel positions (row * cols + col)
     uint8_t* mask1;     // [mask_stride] block masks of levels 1 and 2 (+ the discarded mask after the last level)
-    uint8_t* picked;    // [S0] 0 or the level (1-based) that picked the pixel
+    uint8_t* picked;    // [S0] 0 or (round << 2 | level + 1) of the pick
     DsoState* state;    // [1]
     int n_regions, max_stride, mask_stride;
 };
@@ -68,7 +68,13 @@ struct PixelPlanes {
     float* v;   // < 0 = Unknown
     int off[VORS_MAX_LEVELS];
     int stride;
+    // compaction workspace: usable pixels per chunk of VORS_CHUNK_PX pixels, [pair][chunks_total]; level l owns chunks
+    // chunk_off[l] .. chunk_off[l + 1]
+    int* counts;
+    int chunk_off[VORS_MAX_LEVELS + 1];
+    int chunks_total;
 };
+constexpr int VORS_CHUNK_PX = 1024;
 
 // Image pyramid of a batch: level 0 is the caller's buffer (zero copy), levels >= 1 live in `upper`.
 struct Pyramid {
