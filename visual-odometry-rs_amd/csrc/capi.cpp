@@ -153,7 +153,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
-                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts};
+                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used};
     for (void* p : extra)
         if (p) (void)hipFree(p);
     for (int st = 0; st < 4; ++st) {
@@ -258,6 +258,7 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->pp.iz, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.counts, np * b->pp.chunks_total, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {
@@ -452,7 +453,13 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     if (!b || !n_out) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     const LevelGeom& lg = b->g.lv[level];
-    const size_t n = (size_t)lg.n_slots;
+    size_t n = (size_t)lg.n_slots;
+    HIP_TRY(hipDeviceSynchronize());
+    if (b->rec.n_used) {  // generic-mask mode: the level's slots are compacted, the rest is stale
+        int used = 0;
+        HIP_TRY(hipMemcpy(&used, b->rec.n_used + (size_t)pair * VORS_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+        n = (size_t)std::min(std::max(used, 0), lg.n_slots);
+    }
     std::vector<float4> A(n), B(n);
     std::vector<float2> C(n);
     std::vector<uint32_t> XY(n);
@@ -467,7 +474,7 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
         HIP_TRY(dC.alloc(n * 8));
         HIP_TRY(dXY.alloc(n * 4));
         HIP_TRY(dIZ.alloc(n * 4));
-        Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr, nullptr};
+        Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr, nullptr, nullptr};
         launch_dense_materialize(b->g, level, pair, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, out, nullptr);
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(A.data(), dA.p, n * sizeof(float4), hipMemcpyDeviceToHost));
@@ -741,7 +748,7 @@ static vors_status upload_obs(const vors_obs* o, const float model7[7], ObsDev& 
     }
     HIP_TRY(hipMemcpyAsync(d.model.p, model7, 28, hipMemcpyHostToDevice, s));
     d.k = Intr{o->cu, o->cv, o->fu, o->fv, o->skew};
-    d.rec = Records{d.A.as<float4>(), d.B.as<float4>(), d.C.as<float2>(), d.XY.as<uint32_t>(), d.IZ.as<float>(), nullptr, nullptr};
+    d.rec = Records{d.A.as<float4>(), d.B.as<float4>(), d.C.as<float2>(), d.XY.as<uint32_t>(), d.IZ.as<float>(), nullptr, nullptr, nullptr};
     launch_records_from_obs(d.k, o->rows, o->cols, d.tmpl.as<uint8_t>(), o->n, d.xy.as<int32_t>(), d.iz.as<float>(),
                             d.jac.as<float>(), d.rec, s);
     return VORS_OK;

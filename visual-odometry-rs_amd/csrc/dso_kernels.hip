@@ -28,59 +28,115 @@ __device__ __forceinline__ uint64_t dso_splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-// Per 32x32 region (one workgroup): gradient magnitude (sqrt(((gx^2 + gy^2) / 4) as u16 as f32)) as u16, border 0
-// (gradient.rs:49-65, candidates_dso.rs:42), written to the gmag plane, and the region median sorted[len / 2] through a
-// 256-bin histogram (dso.rs:307-325). Also clears the pick stamps of the previous keyframe.
-__global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws) {
-    __shared__ int hist[256];
-    __shared__ int s_tot[4];
+// Per 32x32 region (one WAVEFRONT, four regions per workgroup, no workgroup barrier): gradient magnitude
+// (sqrt(((gx^2 + gy^2) / 4) as u16 as f32)) as u16, border 0 (gradient.rs:49-65, candidates_dso.rs:42), written to the gmag plane, and
+// the region median sorted[len / 2] through a wave-private 256-bin histogram in LDS (dso.rs:307-325). Also clears the pick stamps of the
+// previous keyframe. A lane owns 4 consecutive pixels in each of 4 rows (row = lane / 8 + 8 * pass).
+__device__ __forceinline__ void dso_hist_add(int* hist, int v, bool active) {
+    // most of a region usually shares one value (flat image areas): the first active lane's value is added once for the whole
+    // wavefront, the remaining lanes fall back to LDS atomics
+    const unsigned long long act = __ballot(active);
+    if (act == 0) return;
+    const int lead = __builtin_amdgcn_readlane(v, __builtin_ctzll(act));
+    const unsigned long long same = __ballot(active && v == lead);
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) atomicAdd(&hist[lead], __popcll(same));
+    if (active && v != lead) atomicAdd(&hist[v], 1);
+}
+__global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws, bool wide) {
+    __shared__ int s_hist[4][256];
     const int pair = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int region = blockIdx.x * 4 + wave;
+    if (region >= ws.n_regions) return;
+    int* hist = s_hist[wave];
     const int rows = g.lv[0].rows, cols = g.lv[0].cols;
     const int rc = (cols + DSO_REGION - 1) / DSO_REGION;
-    const int ri = blockIdx.x / rc, rj = blockIdx.x - ri * rc;
+    const int ri = region / rc, rj = region - ri * rc;
     const int h = min(DSO_REGION, rows - ri * DSO_REGION), w = min(DSO_REGION, cols - rj * DSO_REGION);
-    hist[threadIdx.x] = 0;
-    __syncthreads();
+    *reinterpret_cast<int4*>(&hist[4 * lane]) = make_int4(0, 0, 0, 0);
     const uint8_t* img = kf0 + (size_t)pair * g.S0;
     uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
     uint8_t* pk = ws.picked + (size_t)pair * g.S0;
-    // thread -> 4 consecutive pixels of one region row (8 threads per row, 32 rows per pass)
-    const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
-    const int y = ri * DSO_REGION + ly;
-    if (ly < h) {
+    const int lx0 = (lane & 7) * 4, x0 = rj * DSO_REGION + lx0;
+    int out[4][4];
+    if (wide) {  // cols % 4 == 0 and 4-byte aligned planes: a lane's 4 pixels are one dword in every plane
+        uint32_t up[4], dn[4], mid[4];
+        int left[4], right[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lx = lx0 + k, x = rj * DSO_REGION + lx;
-            if (lx < w) {
-                int out = 0;
-                if (x > 0 && y > 0 && x < cols - 1 && y < rows - 1) {
-                    const uint8_t* p = img + (size_t)y * cols + x;
-                    const int gx = (int)p[1] - (int)p[-1], gy = (int)p[cols] - (int)p[-cols];
-                    out = (int)sqrtf((float)((gx * gx + gy * gy) / 4));  // <= 180
+        for (int ps = 0; ps < 4; ++ps) {
+            const int ly = (lane >> 3) + 8 * ps, y = ri * DSO_REGION + ly;
+            const bool in = ly < h && lx0 < w && y > 0 && y < rows - 1;
+            const size_t o = (size_t)y * cols + x0;
+            up[ps] = in ? *reinterpret_cast<const uint32_t*>(img + o - cols) : 0u;
+            dn[ps] = in ? *reinterpret_cast<const uint32_t*>(img + o + cols) : 0u;
+            mid[ps] = in ? *reinterpret_cast<const uint32_t*>(img + o) : 0u;
+            left[ps] = (in && x0 > 0) ? img[o - 1] : 0;
+            right[ps] = (in && x0 + 4 < cols) ? img[o + 4] : 0;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int ly = (lane >> 3) + 8 * ps, y = ri * DSO_REGION + ly;
+            const bool own = ly < h && lx0 < w, in = own && y > 0 && y < rows - 1;
+            const int row[6] = {left[ps], (int)(mid[ps] & 0xff), (int)((mid[ps] >> 8) & 0xff), (int)((mid[ps] >> 16) & 0xff), (int)(mid[ps] >> 24), right[ps]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gx = row[k + 2] - row[k], gy = (int)((dn[ps] >> (8 * k)) & 0xff) - (int)((up[ps] >> (8 * k)) & 0xff);
+                const int x = x0 + k;
+                out[ps][k] = (in && x > 0 && x < cols - 1) ? (int)sqrtf((float)((gx * gx + gy * gy) / 4)) : 0;  // <= 180
+            }
+            if (own) {
+                const size_t o = (size_t)y * cols + x0;
+                *reinterpret_cast<uint32_t*>(gm + o) =
+                    (uint32_t)out[ps][0] | ((uint32_t)out[ps][1] << 8) | ((uint32_t)out[ps][2] << 16) | ((uint32_t)out[ps][3] << 24);
+                *reinterpret_cast<uint32_t*>(pk + o) = 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int ly = (lane >> 3) + 8 * ps, y = ri * DSO_REGION + ly;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lx = lx0 + k, x = x0 + k;
+                int v = 0;
+                if (ly < h && lx < w) {
+                    const size_t o = (size_t)y * cols + x;
+                    if (x > 0 && y > 0 && x < cols - 1 && y < rows - 1) {
+                        const uint8_t* p = img + o;
+                        const int gx = (int)p[1] - (int)p[-1], gy = (int)p[cols] - (int)p[-cols];
+                        v = (int)sqrtf((float)((gx * gx + gy * gy) / 4));
+                    }
+                    gm[o] = (uint8_t)v;
+                    pk[o] = 0;
                 }
-                gm[(size_t)y * cols + x] = (uint8_t)out;
-                pk[(size_t)y * cols + x] = 0;
-                atomicAdd(&hist[out], 1);
+                out[ps][k] = v;
             }
         }
     }
-    __syncthreads();
-    // first bin whose inclusive prefix count exceeds len / 2
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mine = hist[threadIdx.x];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dso_hist_add(hist, out[ps][k], (lane >> 3) + 8 * ps < h && lx0 + k < w);
+    // first bin whose inclusive prefix count exceeds len / 2 (LDS operations of one wavefront complete in order)
+    const int4 b = *reinterpret_cast<const int4*>(&hist[4 * lane]);
+    const int mine = b.x + b.y + b.z + b.w;
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o);
         if (lane >= o) incl += v;
     }
-    if (lane == 63) s_tot[wave] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < wave; ++q) woff += s_tot[q];
-    incl += woff;
-    const int k = (h * w) / 2;
-    if (incl > k && incl - mine <= k) ws.median[(size_t)pair * ws.n_regions + blockIdx.x] = (uint16_t)threadIdx.x;
+    const int kmed = (h * w) / 2;
+    if (incl > kmed && incl - mine <= kmed) {
+        int acc = incl - mine, med = 4 * lane;
+        const int bins[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (acc <= kmed && acc + bins[q] > kmed) med = 4 * lane + q;
+            acc += bins[q];
+        }
+        ws.median[(size_t)pair * ws.n_regions + region] = (uint16_t)med;
+    }
 }
 
 // All rounds of one pair in one workgroup (dso.rs:98-147): region thresholds, then up to three rounds of
@@ -234,32 +290,50 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
     }
     if (threadIdx.x == 0) ws.state[pair] = st;
 }
-__global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uint8_t* __restrict__ mask_out) {
-    const int pair = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.S0) return;
-    const DsoState st = ws.state[pair];
-    const int stamp = ws.picked[(size_t)pair * g.S0 + t];
+__device__ __forceinline__ uint8_t dso_final_mask(const DsoState& st, int stamp, int t, int cols) {
     bool m = (stamp & 3) != 0 && (stamp >> 2) == st.final_round;
-    if (m && st.random_keep >= 0) {
-        const int cols = g.lv[0].cols;
+    if (m && st.random_keep >= 0) {  // random sub-sampling branch (dso.rs:140-143), counter-hash instead of thread_rng
         const int i = t / cols, j = t - i * cols;
         const uint8_t r = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)i << 32) | (uint32_t)j)) & 0xff);
         m = r <= (uint8_t)st.random_keep;
     }
-    mask_out[(size_t)pair * g.S0 + t] = m ? 1 : 0;
+    return m ? 1 : 0;
+}
+// 16 consecutive pixels per thread (one 16-byte load and store when the planes allow it).
+__global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uint8_t* __restrict__ mask_out) {
+    const int pair = blockIdx.y;
+    const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (t0 >= g.S0) return;
+    const DsoState st = ws.state[pair];
+    const int cols = g.lv[0].cols;
+    const size_t o = (size_t)pair * g.S0 + t0;
+    if (g.S0 % 16 == 0) {
+        const uint4 pk = *reinterpret_cast<const uint4*>(ws.picked + o);
+        uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w}, out[4] = {0, 0, 0, 0};
+        if ((pk.x | pk.y | pk.z | pk.w) != 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int stamp = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+                if (stamp) out[k >> 2] |= (uint32_t)dso_final_mask(st, stamp, t0 + k, cols) << (8 * (k & 3));
+            }
+        }
+        *reinterpret_cast<uint4*>(mask_out + o) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int k = 0; k < 16 && t0 + k < g.S0; ++k) mask_out[o + k] = dso_final_mask(st, ws.picked[o + k], t0 + k, cols);
+    }
 }
 
 void launch_dso_mask(const Geom& g, Pyramid kf, DsoWs ws, uint8_t* mask_out, int n_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3(ws.n_regions, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+    const bool wide_img = g.lv[0].cols % 4 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 4 == 0;
+    hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
     hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(1024), 0, s, g, ws);
-    hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 255) / 256, n_pairs), dim3(256), 0, s, g, ws, mask_out);
+    hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 4095) / 4096, n_pairs), dim3(256), 0, s, g, ws, mask_out);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
 // usable pixels compacted in raster order into the record planes (deterministic: per-chunk counts, then prefix sums). The LM
-// kernel then runs its record path over `capacity` slots per level and skips the empty tail.
+// kernel then runs its record path over the slots in use (Records::n_used).
 // ------------------------------------------------------------------------------------------------------------
 // Level-0 inverse depth is never stored: zip_mask_map + from_depth (helper.rs:40-47, inverse_depth.rs:24-29) evaluated where needed.
 __device__ __forceinline__ float level0_idepth(const Geom& g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask, size_t i) {
@@ -321,6 +395,62 @@ __global__ __launch_bounds__(256) void mask_idepth_halve_kernel(Geom g, int l, c
     pp.iz[o] = od;
     pp.v[o] = ov;
 }
+// Level 1 when cols(level 0) % 16 == 0: 8 consecutive level-1 pixels per thread, the 2 x 16 mask bytes below them in two loads;
+// depth is only read under set mask bytes (candidates are sparse).
+__global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                                       PixelPlanes pp) {
+    const int pair = blockIdx.y;
+    const int rows = g.lv[1].rows, cols = g.lv[1].cols, fc = g.lv[0].cols;
+    const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (t0 >= rows * cols) return;
+    const int y = t0 / cols, x0 = t0 - y * cols;
+    const size_t cb = (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x0;
+    const uint4 m0 = *reinterpret_cast<const uint4*>(mask + cb), m1 = *reinterpret_cast<const uint4*>(mask + cb + fc);
+    float od[8], ov[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        od[k] = __builtin_nanf("");
+        ov[k] = -1.0f;
+    }
+    if ((m0.x | m0.y | m0.z | m0.w | m1.x | m1.y | m1.z | m1.w) != 0) {
+        const uint32_t w0[4] = {m0.x, m0.y, m0.z, m0.w}, w1[4] = {m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // children a = (2y, 2x), b = (2y+1, 2x), c = (2y, 2x+1), d = (2y+1, 2x+1): bytes 2k, 2k+1 of the two rows
+            const uint32_t top = (w0[k >> 1] >> (16 * (k & 1))) & 0xffffu, bot = (w1[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            if ((top | bot) == 0) continue;
+            const bool mk[4] = {(top & 0xff) != 0, (bot & 0xff) != 0, (top >> 8) != 0, (bot >> 8) != 0};
+            const size_t idx[4] = {cb + 2 * k, cb + fc + 2 * k, cb + 2 * k + 1, cb + fc + 2 * k + 1};
+            float dv[4];
+            int n = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (!mk[m]) continue;
+                const uint16_t dz = depth[idx[m]];
+                if (dz != 0) dv[n++] = g.depth_scale / (float)dz;
+            }
+            const float v = g.idepth_variance;
+            if (n == 1) {
+                od[k] = dv[0];
+                ov[k] = v;
+            } else if (n == 2) {
+                ov[k] = v + v;
+                od[k] = (dv[0] * v + dv[1] * v) / ov[k];
+            } else if (n == 3) {
+                ov[k] = v + v + v;
+                od[k] = (dv[0] * v + dv[1] * v + dv[2] * v) / ov[k];
+            } else if (n == 4) {
+                ov[k] = v + v + v + v;
+                od[k] = (dv[0] * v + dv[1] * v + dv[2] * v + dv[3] * v) / ov[k];
+            }
+        }
+    }
+    const size_t o = (size_t)pair * pp.stride + pp.off[1] + t0;
+    reinterpret_cast<float4*>(pp.iz + o)[0] = make_float4(od[0], od[1], od[2], od[3]);
+    reinterpret_cast<float4*>(pp.iz + o)[1] = make_float4(od[4], od[5], od[6], od[7]);
+    reinterpret_cast<float4*>(pp.v + o)[0] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    reinterpret_cast<float4*>(pp.v + o)[1] = make_float4(ov[4], ov[5], ov[6], ov[7]);
+}
 __device__ __forceinline__ float generic_idepth(const Geom& g, const PixelPlanes& pp, const uint16_t* __restrict__ depth,
                                                 const uint8_t* __restrict__ mask, int pair, int l, int t) {
     if (l == 0) return level0_idepth(g, depth, mask, (size_t)pair * g.S0 + t);
@@ -337,12 +467,46 @@ __device__ __forceinline__ void generic_write_record(const Records& rec, size_t 
     rec.XY[slot] = (uint32_t)x | ((uint32_t)y << 16);
     rec.IZ[slot] = iz;
 }
-// Chunk c of a pair covers VORS_CHUNK_PX consecutive pixels (raster order) of one level: count pass, then a record pass in which every
-// workgroup sums the counts of the chunks before it in its level (<= 300 values at 640x480) to get its first slot.
+// Chunk c of a pair covers VORS_CHUNK_PX consecutive pixels (raster order) of one level, 16 consecutive pixels per thread: count pass,
+// then a record pass in which every workgroup sums the counts of the chunks before it in its level to get its first slot.
 __device__ __forceinline__ int chunk_level(const PixelPlanes& pp, int L, int c) {
     int l = 0;
     while (l + 1 < L && c >= pp.chunk_off[l + 1]) ++l;
     return l;
+}
+// bit k set <=> pixel t0 + k of level l has a known inverse depth
+__device__ __forceinline__ unsigned usable16(const Geom& g, const PixelPlanes& pp, const uint16_t* __restrict__ depth,
+                                             const uint8_t* __restrict__ mask, int pair, int l, int t0, int n) {
+    unsigned vb = 0;
+    if (t0 >= n) return 0;
+    if (l == 0) {
+        const size_t o = (size_t)pair * g.S0 + t0;
+        if (g.S0 % 16 == 0) {
+            const uint4 m = *reinterpret_cast<const uint4*>(mask + o);
+            if ((m.x | m.y | m.z | m.w) == 0) return 0;
+            const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (((w[k >> 2] >> (8 * (k & 3))) & 0xff) != 0 && depth[o + k] != 0) vb |= 1u << k;
+        } else {
+            for (int k = 0; k < 16 && t0 + k < n; ++k)
+                if (mask[o + k] != 0 && depth[o + k] != 0) vb |= 1u << k;
+        }
+    } else {
+        const float* iz = pp.iz + (size_t)pair * pp.stride + pp.off[l] + t0;  // 16-byte aligned: stride, off and t0 are multiples of 4
+        if (t0 + 16 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 z = reinterpret_cast<const float4*>(iz)[q];
+                vb |= (z.x == z.x ? 1u : 0u) << (4 * q) | (z.y == z.y ? 2u : 0u) << (4 * q) | (z.z == z.z ? 4u : 0u) << (4 * q) |
+                      (z.w == z.w ? 8u : 0u) << (4 * q);
+            }
+        } else {
+            for (int k = 0; t0 + k < n; ++k)
+                if (iz[k] == iz[k]) vb |= 1u << k;
+        }
+    }
+    return vb;
 }
 __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                              PixelPlanes pp) {
@@ -350,14 +514,10 @@ __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16
     const int pair = blockIdx.y, c = blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int n = g.lv[l].rows * g.lv[l].cols;
-    const int base = (c - pp.chunk_off[l]) * VORS_CHUNK_PX;
-    int cnt = 0;
+    const int t0 = (c - pp.chunk_off[l]) * VORS_CHUNK_PX + threadIdx.x * 16;
+    int cnt = __popc(usable16(g, pp, depth, mask, pair, l, t0, n));
 #pragma unroll
-    for (int k = 0; k < VORS_CHUNK_PX / 256; ++k) {
-        const int t = base + k * 256 + threadIdx.x;
-        const float z = t < n ? generic_idepth(g, pp, depth, mask, pair, l, t) : __builtin_nanf("");
-        cnt += __popcll(__ballot(z == z));
-    }
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) pp.counts[(size_t)pair * pp.chunks_total + c] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -365,8 +525,7 @@ __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16
 __global__ __launch_bounds__(256) void generic_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                                PixelPlanes pp, Records rec) {
-    __shared__ int s_wave[4];
-    __shared__ int s_sub[VORS_CHUNK_PX / 256][4];
+    __shared__ int s_before[4], s_wave[4];
     const int pair = blockIdx.y, c = blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int rows = g.lv[l].rows, cols = g.lv[l].cols, n = rows * cols, cap = g.lv[l].n_slots;
@@ -379,46 +538,46 @@ __global__ __launch_bounds__(256) void generic_records_kernel(Geom g, const uint
     for (int q = pp.chunk_off[l] + threadIdx.x; q < c; q += 256) before_chunks += counts[q];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) before_chunks += __shfl_xor(before_chunks, o);
-    if (lane == 0) s_wave[wave] = before_chunks;
-    const int base = (c - pp.chunk_off[l]) * VORS_CHUNK_PX;
-    float z[VORS_CHUNK_PX / 256];
-    int before[VORS_CHUNK_PX / 256];
+    const int t0 = (c - pp.chunk_off[l]) * VORS_CHUNK_PX + threadIdx.x * 16;
+    unsigned vb = usable16(g, pp, depth, mask, pair, l, t0, n);
+    // exclusive prefix of the per-thread counts over the workgroup
+    const int mine = __popc(vb);
+    int incl = mine;
 #pragma unroll
-    for (int k = 0; k < VORS_CHUNK_PX / 256; ++k) {
-        const int t = base + k * 256 + threadIdx.x;
-        z[k] = t < n ? generic_idepth(g, pp, depth, mask, pair, l, t) : __builtin_nanf("");
-        const unsigned long long m = __ballot(z[k] == z[k]);
-        before[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (lane == 0) s_sub[k][wave] = __popcll(m);
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) s_wave[wave] = incl;
+    if (lane == 0) s_before[wave] = before_chunks;
     __syncthreads();
-    int run = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-#pragma unroll
-    for (int k = 0; k < VORS_CHUNK_PX / 256; ++k) {
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_sub[k][w];
-        const int slot = run + woff + before[k];
-        const int t = base + k * 256 + threadIdx.x;
-        if (z[k] == z[k] && slot < cap) {
+    int slot = s_before[0] + s_before[1] + s_before[2] + s_before[3] + incl - mine;
+    for (int w = 0; w < wave; ++w) slot += s_wave[w];
+    while (vb) {
+        const int k = __ffs(vb) - 1;
+        vb &= vb - 1;
+        if (slot < cap) {
+            const int t = t0 + k;
             const int y = t / cols, x = t - y * cols;
             int gx, gy;
             grad_at(g, kf0, kfu, pair, l, x, y, &gx, &gy);
-            generic_write_record(rec, slot0 + slot, g.lv[l].k, x, y, z[k], gx, gy, img[t]);
+            generic_write_record(rec, slot0 + slot, g.lv[l].k, x, y, generic_idepth(g, pp, depth, mask, pair, l, t), gx, gy, img[t]);
         }
-        run += s_sub[k][0] + s_sub[k][1] + s_sub[k][2] + s_sub[k][3];
+        ++slot;
     }
-    // the last chunk of the level marks the unused tail of the level's slots as empty
-    if (c + 1 == pp.chunk_off[l + 1])
-        for (int k = min(run, cap) + threadIdx.x; k < cap; k += 256) {
-            rec.A[slot0 + k] = make_float4(0.f, 0.f, 0.f, -1.0f);
-            rec.XY[slot0 + k] = VORS_INVALID_XY;
-        }
+    // the last thread of the level's last chunk publishes how many of the level's slots are in use
+    if (c + 1 == pp.chunk_off[l + 1] && threadIdx.x == 255) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l] = min(slot, cap);
 }
 
 void launch_keyframe_generic(const Geom& g, Pyramid kf, const uint16_t* depth, const uint8_t* mask, PixelPlanes pp, Records rec,
                              int n_pairs, hipStream_t s) {
-    for (int l = 1; l < g.L; ++l)
-        hipLaunchKernelGGL(mask_idepth_halve_kernel, dim3((g.lv[l].rows * g.lv[l].cols + 255) / 256, n_pairs), dim3(256), 0, s, g, l, depth, mask, pp);
+    for (int l = 1; l < g.L; ++l) {
+        const int n = g.lv[l].rows * g.lv[l].cols;
+        if (l == 1 && g.lv[0].cols % 16 == 0)
+            hipLaunchKernelGGL(mask_idepth_level1_wide_kernel, dim3((n / 8 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, mask, pp);
+        else
+            hipLaunchKernelGGL(mask_idepth_halve_kernel, dim3((n + 255) / 256, n_pairs), dim3(256), 0, s, g, l, depth, mask, pp);
+    }
     hipLaunchKernelGGL(generic_count_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, depth, mask, pp);
     hipLaunchKernelGGL(generic_records_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, kf.level0, kf.upper, depth, mask, pp, rec);
 }

@@ -45,6 +45,7 @@ struct Records {
     float* IZ;
     float* V;  // dense mode only: fused weight ("variance") plane, < 0 = Unknown
     const float2* LUT;  // dense mode only: depth u16 -> (scale / depth, 1 / (scale / depth)), exact
+    int* n_used;  // generic-mask mode only: [pair][VORS_MAX_LEVELS] slots in use per level (compacted, no holes); else NULL
 };
 
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
@@ -74,7 +75,7 @@ struct PixelPlanes {
     int chunk_off[VORS_MAX_LEVELS + 1];
     int chunks_total;
 };
-constexpr int VORS_CHUNK_PX = 1024;
+constexpr int VORS_CHUNK_PX = 4096;  // 256 threads x 16 consecutive pixels
 
 // Image pyramid of a batch: level 0 is the caller's buffer (zero copy), levels >= 1 live in `upper`.
 struct Pyramid {

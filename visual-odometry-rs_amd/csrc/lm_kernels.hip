@@ -633,7 +633,7 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
     } else {
         const size_t rb = (size_t)pair * g.slots_total + lg.slot_off;
         RecSrc src{rec.A + rb, rec.B + rb, rec.C + rb};
-        f(src, lg.n_slots);
+        f(src, rec.n_used ? __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]) : lg.n_slots);
     }
 }
 
@@ -710,7 +710,8 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
             const size_t rb = (size_t)pair * g.slots_total + g.lv[lvl].slot_off;
             const float4* A = rec.A + rb;
             const uint32_t* XY = rec.XY + rb;
-            for (int i = threadIdx.x; i < g.lv[lvl].n_slots; i += BLOCK) {
+            const int n_slots = rec.n_used ? rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl] : g.lv[lvl].n_slots;
+            for (int i = threadIdx.x; i < n_slots; i += BLOCK) {
                 const float4 a = A[i];
                 if (a.w >= 0.f) {
                     const uint32_t p = XY[i];
@@ -763,7 +764,11 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
                 }
             } else {
                 const float4* A = rec.A + (size_t)pair * g.slots_total + lg.slot_off;
-                for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (A[i].w >= 0.f) ? 1.0f : 0.f;
+                if (rec.n_used) {
+                    if (threadIdx.x == 0) n = (float)rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
+                } else {
+                    for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (A[i].w >= 0.f) ? 1.0f : 0.f;
+                }
             }
             block_sum2<BLOCK>(n, dummy, s);
             if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = (int)n;
