@@ -6,7 +6,7 @@ import numpy as np, torch
 import vors_amd as V
 V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", os.environ.get("VLIB", "libvors_hip_prof.so"))
 from oracle import oracle as O
-rows, cols, L = 480, 640, 6
+rows, cols, L = 480, 640, int(os.environ.get("LEVELS", "6"))
 intr = O.scaled_intrinsics(rows, cols)
 n = int(os.environ.get("PAIRS", "256"))
 kg, kd, cg, _, gt = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
@@ -19,6 +19,7 @@ for mode in (0, 1):
         for _ in range(3): b.track_pairs(kg, kd, cg, poses, status, stats)
         torch.cuda.synchronize()
         st = V.decode_stats(stats)
+        if L <= 6: print(f"   epilogue mean {st['energy'][:, 6].mean():.1f} us, whole workgroup mean {st['energy'][:, 7].mean():.1f} max {st['energy'][:, 7].max():.1f} us")
         us = st["energy"][:, :L]
         it = st["nb_iter"][:, :L]
         print(f"mode {mode} block {blk}: lm kernel {b.kernel_times('lm')[-1]*1e3:.0f} us; per-level mean us {np.round(us.mean(0),1)} max {np.round(us.max(0),1)}; "

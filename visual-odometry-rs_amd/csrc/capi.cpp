@@ -48,6 +48,8 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     if (cfg->nb_levels < 1 || cfg->nb_levels > VORS_MAX_LEVELS)
         return fail(VORS_ERR_INVALID_ARGUMENT, "nb_levels must be in [1, " + std::to_string(VORS_MAX_LEVELS) + "]");
     if (rows < 2 || cols < 2 || rows > 65535 || cols > 65535) return fail(VORS_ERR_INVALID_ARGUMENT, "rows/cols must be in [2, 65535]");
+    if ((long long)rows * cols > (1ll << 28))  // the kernels address a level with 32-bit byte offsets
+        return fail(VORS_ERR_INVALID_ARGUMENT, "rows * cols must not exceed 2^28 pixels");
     if (cfg->candidates_mode != VORS_CANDIDATES_COARSE_TO_FINE && cfg->candidates_mode != VORS_CANDIDATES_DENSE &&
         cfg->candidates_mode != VORS_CANDIDATES_DSO)
         return fail(VORS_ERR_INVALID_ARGUMENT, "unknown candidates_mode");
@@ -222,6 +224,7 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     if (g.mode == VORS_CANDIDATES_DENSE) {
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.V, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
     } else {
         if (e == hipSuccess) e = dmalloc(&b->rec.A, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.B, slots, &b->bytes);
@@ -455,7 +458,7 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     const LevelGeom& lg = b->g.lv[level];
     size_t n = (size_t)lg.n_slots;
     HIP_TRY(hipDeviceSynchronize());
-    if (b->rec.n_used) {  // generic-mask mode: the level's slots are compacted, the rest is stale
+    if (b->g.mode == VORS_CANDIDATES_DSO) {  // generic-mask mode: the level's slots are compacted, the rest is stale
         int used = 0;
         HIP_TRY(hipMemcpy(&used, b->rec.n_used + (size_t)pair * VORS_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
         n = (size_t)std::min(std::max(used, 0), lg.n_slots);

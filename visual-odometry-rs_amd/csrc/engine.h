@@ -45,7 +45,8 @@ struct Records {
     float* IZ;
     float* V;  // dense mode only: fused weight ("variance") plane, < 0 = Unknown
     const float2* LUT;  // dense mode only: depth u16 -> (scale / depth, 1 / (scale / depth)), exact
-    int* n_used;  // generic-mask mode only: [pair][VORS_MAX_LEVELS] slots in use per level (compacted, no holes); else NULL
+    int* n_used;  // [pair][VORS_MAX_LEVELS]; generic-mask mode: slots in use per level (compacted, no holes); dense mode: usable points
+                  // per level counted by the keyframe stage (level 0 only when L >= 2); coarse-to-fine mode: NULL
 };
 
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.

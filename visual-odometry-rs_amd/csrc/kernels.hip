@@ -323,49 +323,111 @@ __device__ __forceinline__ void fuse_dso_mean(const float dv_in[4], const float 
         *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2] + dv[3] * vv[3]) / *ov;
     }
 }
-// level 1 straight from the depth map (from_depth, inverse_depth.rs:24-29, fused with the first halve)
+// Wave-aggregated integer counters: usable points per (pair, level), published for the LM kernel's statistics.
+__device__ __forceinline__ void count_add(int* counter, int n) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0 && n != 0) atomicAdd(counter, n);
+}
+// level 1 straight from the depth map (from_depth, inverse_depth.rs:24-29, fused with the first halve). Also counts the usable
+// pixels of level 0 (non-zero depth; the odd trailing row / column of level 0 has no level-1 parent and is counted by the
+// threads of the last level-1 row / column) and of level 1.
 __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     const int pair = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[1].rows, cols = g.lv[1].cols;
-    if (t >= rows * cols) return;
-    const int y = t / cols, x = t - y * cols;
-    const int fc = g.lv[0].cols;
-    const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x;
-    // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1) with i=row, j=col   (multires.rs:80-83)
-    const uint16_t dz[4] = {p[0], p[fc], p[1], p[fc + 1]};
-    float dv[4], vv[4];
+    int n0 = 0, n1 = 0;
+    if (t < rows * cols) {
+        const int y = t / cols, x = t - y * cols;
+        const int fr = g.lv[0].rows, fc = g.lv[0].cols;
+        const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x;
+        // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1) with i=row, j=col   (multires.rs:80-83)
+        const uint16_t dz[4] = {p[0], p[fc], p[1], p[fc + 1]};
+        float dv[4], vv[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
-        vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
+        for (int m = 0; m < 4; ++m) {
+            dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+            vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
+            n0 += dz[m] != 0;
+        }
+        const bool last_x = x == cols - 1 && (fc & 1), last_y = y == rows - 1 && (fr & 1);
+        if (last_x) n0 += (p[2] != 0) + (p[fc + 2] != 0);
+        if (last_y) n0 += (p[2 * fc] != 0) + (p[2 * fc + 1] != 0);
+        if (last_x && last_y) n0 += p[2 * fc + 2] != 0;
+        float od, ov;
+        fuse_dso_mean(dv, vv, &od, &ov);
+        const size_t slot = (size_t)pair * g.slots_total + g.lv[1].slot_off + t;
+        rec.IZ[slot] = od;
+        rec.V[slot] = ov;
+        n1 = ov >= 0.f;
     }
-    float od, ov;
-    fuse_dso_mean(dv, vv, &od, &ov);
-    const size_t slot = (size_t)pair * g.slots_total + g.lv[1].slot_off + t;
-    rec.IZ[slot] = od;
-    rec.V[slot] = ov;
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
+}
+// Same, 4 level-1 pixels per thread when cols(level 0) % 8 == 0 and the depth rows are 16-byte aligned: two 16-byte loads, two
+// 16-byte stores.
+__global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
+    const int pair = blockIdx.y;
+    const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int rows = g.lv[1].rows, cols = g.lv[1].cols;
+    int n0 = 0, n1 = 0;
+    if (t0 < rows * cols) {
+        const int y = t0 / cols, x0 = t0 - y * cols;
+        const int fr = g.lv[0].rows, fc = g.lv[0].cols;
+        const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x0;
+        const uint4 r0 = *reinterpret_cast<const uint4*>(p), r1 = *reinterpret_cast<const uint4*>(p + fc);
+        const uint32_t w0[4] = {r0.x, r0.y, r0.z, r0.w}, w1[4] = {r1.x, r1.y, r1.z, r1.w};
+        float od[4], ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t dz[4] = {w0[k] & 0xffffu, w1[k] & 0xffffu, w0[k] >> 16, w1[k] >> 16};  // a, b, c, d
+            float dv[4], vv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+                vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
+                n0 += dz[m] != 0;
+            }
+            fuse_dso_mean(dv, vv, &od[k], &ov[k]);
+            n1 += ov[k] >= 0.f;
+        }
+        if (y == rows - 1 && (fr & 1)) {  // odd trailing row of level 0 (no odd column: fc % 8 == 0)
+            const uint4 r2 = *reinterpret_cast<const uint4*>(p + 2 * fc);
+            const uint32_t w2[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) n0 += ((w2[k] & 0xffffu) != 0) + ((w2[k] >> 16) != 0);
+        }
+        const size_t slot = (size_t)pair * g.slots_total + g.lv[1].slot_off + t0;
+        *reinterpret_cast<float4*>(rec.IZ + slot) = make_float4(od[0], od[1], od[2], od[3]);
+        *reinterpret_cast<float4*>(rec.V + slot) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
 }
 __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, Records rec) {
     const int pair = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[l].rows, cols = g.lv[l].cols;
-    if (t >= rows * cols) return;
-    const int y = t / cols, x = t - y * cols;
-    const int fc = g.lv[l - 1].cols;
-    const size_t cb = (size_t)pair * g.slots_total + g.lv[l - 1].slot_off + (size_t)(2 * y) * fc + 2 * x;
-    const size_t idx[4] = {cb, cb + fc, cb + 1, cb + fc + 1};
-    float dv[4], vv[4];
+    int n = 0;
+    if (t < rows * cols) {
+        const int y = t / cols, x = t - y * cols;
+        const int fc = g.lv[l - 1].cols;
+        const size_t cb = (size_t)pair * g.slots_total + g.lv[l - 1].slot_off + (size_t)(2 * y) * fc + 2 * x;
+        const size_t idx[4] = {cb, cb + fc, cb + 1, cb + fc + 1};
+        float dv[4], vv[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        dv[m] = rec.IZ[idx[m]];
-        vv[m] = rec.V[idx[m]];
+        for (int m = 0; m < 4; ++m) {
+            dv[m] = rec.IZ[idx[m]];
+            vv[m] = rec.V[idx[m]];
+        }
+        float od, ov;
+        fuse_dso_mean(dv, vv, &od, &ov);
+        const size_t slot = (size_t)pair * g.slots_total + g.lv[l].slot_off + t;
+        rec.IZ[slot] = od;
+        rec.V[slot] = ov;
+        n = ov >= 0.f;
     }
-    float od, ov;
-    fuse_dso_mean(dv, vv, &od, &ov);
-    const size_t slot = (size_t)pair * g.slots_total + g.lv[l].slot_off + t;
-    rec.IZ[slot] = od;
-    rec.V[slot] = ov;
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + l, n);
 }
 // Inspection only (vors_batch_get_points in dense mode): materialise the records of ONE level of ONE pair into `out`
 // (planes of n_slots entries, index = y*cols + x), with exactly the arithmetic the LM kernel uses on the fly.
@@ -403,8 +465,15 @@ void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const 
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
     const int n_roots = g.root_rows * g.root_cols;
     if (g.mode == VORS_CANDIDATES_DENSE) {
-        if (g.L >= 2)
-            hipLaunchKernelGGL(dense_idepth_level1_kernel, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+        (void)hipMemsetAsync(rec.n_used, 0, (size_t)n_pairs * VORS_MAX_LEVELS * sizeof(int), s);
+        if (g.L >= 2) {
+            // (slots_total and slot_off are multiples of 4, so the level-1 stores of the wide kernel are 16-byte aligned)
+            const bool wide = g.lv[0].cols % 8 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0;
+            if (wide)
+                hipLaunchKernelGGL(dense_idepth_level1_wide_kernel, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+            else
+                hipLaunchKernelGGL(dense_idepth_level1_kernel, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+        }
         for (int l = 2; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {

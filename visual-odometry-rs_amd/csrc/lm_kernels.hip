@@ -79,13 +79,13 @@ struct RecSrc {
         for (int g = 0; g < 2; ++g) {
             const int i = cur.i + g * BLOCK;
             r.i[g] = i;
-            r.a[g] = (i < n) ? A[i] : make_float4(0.f, 0.f, 0.f, -1.f);
+            r.a[g] = (i < n) ? A[(unsigned)i] : make_float4(0.f, 0.f, 0.f, -1.f);  // 32-bit offsets from the uniform plane bases
         }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const bool v = r.a[g].w >= 0.f;
-            r.b[g] = v ? B[r.i[g]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.c[g] = v ? C[r.i[g]] : make_float2(0.f, 0.f);
+            r.b[g] = v ? B[(unsigned)r.i[g]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.c[g] = v ? C[(unsigned)r.i[g]] : make_float2(0.f, 0.f);
         }
     }
     __device__ __forceinline__ void positions(const Raw& r, Pos p[2]) const {
@@ -225,24 +225,25 @@ struct DenseQuadSrc {
         const int x0 = 4 * c.qx, y = c.y;
         r.x0 = x0;
         r.y = y;
-        const uint8_t* row = kimg + (size_t)y * cols + x0;
-        r.cw = *reinterpret_cast<const uint32_t*>(row);
+        // 32-bit unsigned offsets from workgroup-uniform bases (scalar base + vector offset addressing, no 64-bit VALU arithmetic)
+        const unsigned ucols = (unsigned)cols, o = (unsigned)y * ucols + (unsigned)x0;
+        r.cw = *reinterpret_cast<const uint32_t*>(kimg + o);
         if (LEVEL0) {
             const bool yin = y > 0 && y < rows - 1;
-            r.w1 = *reinterpret_cast<const uint32_t*>(row - (yin ? cols : 0));
-            r.w2 = *reinterpret_cast<const uint32_t*>(row + (yin ? cols : 0));
-            r.w3 = row[x0 > 0 ? -1 : 0];
-            r.w4 = row[x0 + 4 < cols ? 4 : 3];
-            const uint2 dzw = *reinterpret_cast<const uint2*>(depth + (size_t)y * cols + x0);
+            r.w1 = *reinterpret_cast<const uint32_t*>(kimg + (o - (yin ? ucols : 0u)));
+            r.w2 = *reinterpret_cast<const uint32_t*>(kimg + (o + (yin ? ucols : 0u)));
+            r.w3 = kimg[o - (x0 > 0 ? 1u : 0u)];
+            r.w4 = kimg[o + (x0 + 4 < cols ? 4u : 3u)];
+            const uint2 dzw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(depth) + (o << 1));
             r.d0 = dzw.x;
             r.d1 = dzw.y;
             r.d2 = r.d3 = 0;
         } else {
-            const uint8_t* f = kfine + (size_t)(2 * y) * fcols + 2 * x0;
-            const uint2 f0 = *reinterpret_cast<const uint2*>(f);
-            const uint2 f1 = *reinterpret_cast<const uint2*>(f + fcols);
+            const unsigned ufc = (unsigned)fcols, fo = (unsigned)(2 * y) * ufc + (unsigned)(2 * x0);
+            const uint2 f0 = *reinterpret_cast<const uint2*>(kfine + fo);
+            const uint2 f1 = *reinterpret_cast<const uint2*>(kfine + (fo + ufc));
             r.w1 = f0.x; r.w2 = f0.y; r.w3 = f1.x; r.w4 = f1.y;
-            const uint4 z4 = *reinterpret_cast<const uint4*>(iz + (size_t)y * cols + x0);
+            const uint4 z4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(iz) + (o << 2));
             r.d0 = z4.x; r.d1 = z4.y; r.d2 = z4.z; r.d3 = z4.w;
         }
     }
@@ -333,10 +334,10 @@ struct Taps {
     uint32_t top, bot;  // (t00 | t01 << 8), (t10 | t11 << 8)
 };
 __device__ __forceinline__ Taps load_taps(const ImgCtx& c, const Warped& w) {
-    const uint8_t* q = c.img + w.off;
+    const unsigned o = (unsigned)w.off;  // >= 0 by construction; 32-bit offset from the uniform image base
     uint16_t a, b;
-    __builtin_memcpy(&a, q, 2);  // two adjacent bytes per row: one (possibly unaligned) 16-bit load each
-    __builtin_memcpy(&b, q + c.cols, 2);
+    __builtin_memcpy(&a, c.img + o, 2);  // two adjacent bytes per row: one (possibly unaligned) 16-bit load each
+    __builtin_memcpy(&b, c.img + (o + (unsigned)c.cols), 2);
     return Taps{a, b};
 }
 // bilinear (lm_optimizer.rs:236-247, term order as written) + residual + the 29 sums. Returns the residual (NaN if outside).
@@ -648,6 +649,9 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
                                                           float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
                                                           vors_pair_stats* __restrict__ out_stats) {
     __shared__ LmShared s;
+#ifdef VORS_PROFILE_LEVELS
+    const long long t_kernel0 = wall_clock64();
+#endif
     const int pair = blockIdx.x;
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
         bool ok = false;
 #ifdef VORS_PROFILE_LEVELS
         const long long t_level0 = wall_clock64();
+        const long long c_level0 = clock64();
 #endif
         with_level_source<DENSE, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
             ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s);
@@ -674,6 +679,9 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
             out_stats[pair].energy[lvl] = ok ? energy : 0.f;
 #ifdef VORS_PROFILE_LEVELS
             out_stats[pair].energy[lvl] = (float)(wall_clock64() - t_level0) * 0.01f;  // 100 MHz ticks -> microseconds
+#ifdef VORS_PROFILE_CLOCK
+            out_stats[pair].energy[lvl] = (float)(clock64() - c_level0) / ((float)(wall_clock64() - t_level0) * 10.0f);  // shader GHz
+#endif
 #endif
         }
         if (!ok) {
@@ -686,6 +694,9 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
             break;
         }
     }
+#ifdef VORS_PROFILE_LEVELS
+    const long long t_epilogue0 = wall_clock64();
+#endif
     // keyframe test on the coarsest level (inverse_compositional.rs:211-224), with the last lm_model even after a failure
     float flow_sum = 0.f, flow_n = 0.f;
     {
@@ -742,7 +753,9 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
             const LevelGeom lg = g.lv[lvl];
             float n = 0.f, dummy = 0.f;
             if constexpr (DENSE) {
-                if (lvl == 0) {
+                if (rec.n_used && g.L >= 2) {  // counted by the keyframe stage
+                    if (threadIdx.x == 0) n = (float)rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
+                } else if (lvl == 0) {
                     const uint16_t* d = kf_depth + (size_t)pair * g.S0;
                     if ((g.S0 & 7) == 0) {  // 8 depth values per 16-byte load
                         const uint4* d8 = reinterpret_cast<const uint4*>(d);
@@ -779,6 +792,12 @@ __global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* 
                 out_stats[pair].n_points[lvl] = 0;
                 out_stats[pair].energy[lvl] = 0.f;
             }
+#ifdef VORS_PROFILE_LEVELS
+        if (threadIdx.x == 0 && g.L <= VORS_MAX_LEVELS - 2) {
+            out_stats[pair].energy[VORS_MAX_LEVELS - 2] = (float)(wall_clock64() - t_epilogue0) * 0.01f;  // epilogue, microseconds
+            out_stats[pair].energy[VORS_MAX_LEVELS - 1] = (float)(wall_clock64() - t_kernel0) * 0.01f;    // whole workgroup
+        }
+#endif
     }
 }
 
