@@ -642,7 +642,12 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
 // Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
 // ------------------------------------------------------------------------------------------------------------
 template <int BLOCK, bool HUBER, bool DENSE>
-__global__ __launch_bounds__(BLOCK) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+// Register budget: with 256-thread workgroups more resident workgroups per CU hide the latency-bound coarse levels of their
+// neighbours (measured at 4096 pairs: dense 5 waves/SIMD = 96 VGPRs +3.7 %, 6 spills; sparse 6 waves/SIMD +4 %).
+#ifndef VORS_LM_WAVES
+#define VORS_LM_WAVES (BLOCK == 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
+#endif
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_WAVES))) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                           const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                           const uint16_t* __restrict__ kf_depth, Records rec,
                                                           const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
