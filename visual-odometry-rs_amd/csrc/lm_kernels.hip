@@ -266,7 +266,8 @@ struct DenseQuadSrc {
                 r.gy[j] = half_trunc(dn - up) & in;
                 const int dz = (j < 2 ? (l.d0 >> (16 * j)) : (l.d1 >> (16 * (j - 2)))) & 0xffff;
                 r.valid[j] = dz != 0;
-                const float2 zl = lut[dz];  // (scale / dz, 1 / (scale / dz)): inverse_depth.rs:24-29, lm_optimizer.rs:215
+                // (scale / dz, 1 / (scale / dz)): inverse_depth.rs:24-29, lm_optimizer.rs:215
+                const float2 zl = *reinterpret_cast<const float2*>(reinterpret_cast<const uint8_t*>(lut) + ((unsigned)dz << 3));
                 r.izv[j] = zl.x;
                 r.zv[j] = zl.y;
             }
