@@ -123,6 +123,7 @@ struct vors_batch {
     const uint8_t* cur_level0 = nullptr;  // caller's buffer of the last track_current
     const uint16_t* kf_depth = nullptr;   // caller's depth buffer of the last prepare_keyframes (read by the dense LM kernel)
     Records rec{};
+    LmSplitWs split{};
     uint64_t bytes = 0;
     int lm_block = 256;  // threads per frame pair in the LM kernel (256 / 512 / 1024)
     // generic-mask (DSO) mode workspaces
@@ -155,7 +156,8 @@ static void batch_free(vors_batch* b) {
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
-                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used};
+                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used,
+                     b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
     for (void* p : extra)
         if (p) (void)hipFree(p);
     for (int st = 0; st < 4; ++st) {
@@ -262,6 +264,19 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.counts, np * b->pp.chunks_total, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
+    }
+    if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE && !(getenv("VORS_LM_SPLIT") && atoi(getenv("VORS_LM_SPLIT")) == 0)) {
+        // evaluation-synchronous level 0 (lm_kernels.hip): chunks per pair so that large batches get ~16 workgroups per pair and
+        // small ones (down to the single tracker) still spread one evaluation over the chip; a chunk is at least 2048 pixels
+        int chunks = max_pairs >= 1024 ? 16 : (max_pairs >= 128 ? 32 : 64);
+        chunks = std::max(1, std::min(chunks, g.S0 / 2048));
+        if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(1, atoi(ev));
+        b->split.chunks = chunks;
+        if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.list[1], np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)VORS_SPLIT_MAX_EVALS + 2, &b->bytes);
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {
@@ -379,7 +394,7 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
     launch_pyramid(b->g, cur, n_pairs, s);
     STAGE_END(b, 2, s);
     STAGE_BEGIN(b, 3, s);
-    launch_lm_track(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, b->lm_block, s);
+    launch_lm_track(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, b->lm_block, b->split, s);
     STAGE_END(b, 3, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;

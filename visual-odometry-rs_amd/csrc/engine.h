@@ -64,6 +64,28 @@ struct DsoWs {
     DsoState* state;    // [1]
     int n_regions, max_stride, mask_stride;
 };
+// Evaluation-synchronous LM at level 0 (dense mode, lm_kernels.hip "split" path): the coarse levels run in the per-pair
+// kernel, then every level-0 energy evaluation is ONE launch over (active pairs x chunks of the image) followed by a tiny
+// per-pair step launch — all CUs stay busy whatever the pairs' iteration counts.
+struct LmSplitState {  // per pair
+    float model[7];    // kept model (the level's running estimate)
+    float cand[7];     // candidate under evaluation
+    float sums[32];    // sums of the kept state (energy sum, n, g[6], H upper triangle[21])
+    float cur_energy, lm_coef;
+    int nb_iter;
+    int phase;         // 0 init evaluation pending, 1 candidate evaluation pending, 2 level finished, 3 step() failed
+    int went_well;     // 0: a coarser level failed (the pair skips level 0)
+    int pad;
+};
+#define VORS_SPLIT_MAX_EVALS 22  // init + at most 21 steps (nb_iter > 20 stops, lm_optimizer.rs:156-192)
+struct LmSplitWs {
+    LmSplitState* state;  // [pairs]
+    float* partials;      // [pairs][chunks][32]
+    int* list[2];         // active pair lists, ping-pong per evaluation
+    int* count;           // [VORS_SPLIT_MAX_EVALS + 2] active pairs per evaluation
+    int chunks;           // 0 = split path disabled
+};
+
 // Per-pixel inverse-depth planes of the generic-mask keyframe path (all levels).
 struct PixelPlanes {
     float* iz;  // NaN = Unknown
@@ -95,7 +117,7 @@ void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const 
                               hipStream_t s);
 // `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).
 void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
-                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, hipStream_t s);
+                     float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
 // Operator level on explicit observations of one level (device buffers): eval at `model` -> out29 partial sums layout:
 // [0]=sum r^2 (or Huber loss), [1]=n_inside (as float), [2..7]=g, [8..28]=H upper triangle row-wise.
 void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,

@@ -17,6 +17,7 @@
 // residuals are bit-identical to the oracle); explicit fmaf only where the summation order differs anyway.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "device_common.h"
@@ -66,8 +67,8 @@ struct RecSrc {
         int i;
     };
     template <int BLOCK>
-    __device__ __forceinline__ Cursor begin() const {
-        return Cursor{(int)threadIdx.x};
+    __device__ __forceinline__ Cursor begin(int first = 0) const {
+        return Cursor{first + (int)threadIdx.x};
     }
     template <int BLOCK>
     __device__ __forceinline__ Cursor advance(const Cursor& c) const {
@@ -128,8 +129,8 @@ struct DenseSrc {
         bool valid;
     };
     template <int BLOCK>
-    __device__ __forceinline__ Cursor begin() const {
-        const int t = (int)threadIdx.x;
+    __device__ __forceinline__ Cursor begin(int first = 0) const {
+        const int t = first + (int)threadIdx.x;
         const int y = t / cols;
         return Cursor{t, t - y * cols, y};
     }
@@ -206,8 +207,8 @@ struct DenseQuadSrc {
         bool valid[4];
     };
     template <int BLOCK>
-    __device__ __forceinline__ Cursor begin() const {
-        const int t = (int)threadIdx.x;
+    __device__ __forceinline__ Cursor begin(int first = 0) const {
+        const int t = first + (int)threadIdx.x;
         const int y = t / qcols;
         return Cursor{t, t - y * qcols, y};
     }
@@ -430,11 +431,11 @@ __device__ __forceinline__ void process_group(const Src& src, const typename Src
 // of a SIMD do not all stall on the same loads at the top of every iteration.
 template <int BLOCK, bool HUBER, bool WRITE_RES, class Src>
 __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, const ImgCtx& c, const Iso& model, float acc[NACC],
-                                                float* residuals) {
+                                                float* residuals, int first = 0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
     if constexpr (Src::PREFETCH) {
-        typename Src::Cursor cur = src.template begin<BLOCK>();
+        typename Src::Cursor cur = src.template begin<BLOCK>(first);
         if (cur.i >= n_units) return;
         typename Src::Loaded ld;
         src.load(cur, ld);
@@ -451,7 +452,7 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
             cur = nxt;
         }
     } else {
-        for (typename Src::Cursor cur = src.template begin<BLOCK>(); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
+        for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
             typename Src::Raw raw;
             src.template fetch<BLOCK>(cur, n_units, raw);
             process_group<HUBER, WRITE_RES>(src, raw, n_units, c, model, acc, residuals);
@@ -646,14 +647,16 @@ template <int BLOCK, bool HUBER, bool DENSE>
 // Register budget: with 256-thread workgroups more resident workgroups per CU hide the latency-bound coarse levels of their
 // neighbours (measured at 4096 pairs: dense 5 waves/SIMD = 96 VGPRs +3.7 %, 6 spills; sparse 6 waves/SIMD +4 %).
 #ifndef VORS_LM_WAVES
-#define VORS_LM_WAVES (BLOCK == 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
+#define VORS_LM_WAVES (BLOCK <= 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
 #endif
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_WAVES))) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                           const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                           const uint16_t* __restrict__ kf_depth, Records rec,
                                                           const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
                                                           float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
-                                                          vors_pair_stats* __restrict__ out_stats) {
+                                                          vors_pair_stats* __restrict__ out_stats, int mode, LmSplitWs split) {
+    // mode 0: the whole track() of the pair. Split path (dense): mode 1 = levels L-1..1, hands the model over through
+    // split.state; mode 2 = after the level-0 launches: takes the result back, pose + keyframe test + statistics.
     __shared__ LmShared s;
 #ifdef VORS_PROFILE_LEVELS
     const long long t_kernel0 = wall_clock64();
@@ -663,7 +666,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
     bool went_well = true;
-    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
+    if (mode == 2) {  // level 0 has been solved by the evaluation-synchronous launches
+        const LmSplitState* st = split.state + pair;
+        lm_model = iso_uniform(iso_load(st->model));
+        went_well = st->went_well != 0 && st->phase == 2;
+        if (out_stats && threadIdx.x == 0 && st->went_well != 0) {
+            out_stats[pair].nb_iter[0] = st->phase == 2 ? st->nb_iter : 0;
+            out_stats[pair].energy[0] = st->phase == 2 ? st->cur_energy : 0.f;
+        }
+    }
+    for (int lvl = (mode == 2 ? -1 : g.L - 1); lvl >= (mode == 1 ? 1 : 0); --lvl) {
         ImgCtx c;
         c.img = level_ptr(g, cur0, curu, pair, lvl);
         c.rows = g.lv[lvl].rows;
@@ -699,6 +711,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                 }
             break;
         }
+    }
+    if (mode == 1) {
+        if (threadIdx.x == 0) {
+            LmSplitState* st = split.state + pair;
+            iso_store(lm_model, st->model);
+            st->phase = 0;
+            st->nb_iter = 0;
+            st->went_well = went_well ? 1 : 0;
+            if (went_well) split.list[0][atomicAdd(&split.count[0], 1)] = pair;
+        }
+        return;
     }
 #ifdef VORS_PROFILE_LEVELS
     const long long t_epilogue0 = wall_clock64();
@@ -807,34 +830,184 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Split path, level 0 of dense mode: one launch per energy evaluation over (active pairs x chunks), one small launch per
+// step. Same arithmetic per point and the same control flow as solve_level; the sums are formed per chunk (fixed order:
+// thread -> wavefront -> workgroup -> chunks in index order), so results are deterministic.
+// ------------------------------------------------------------------------------------------------------------
+#define SPLIT_BLOCK 256
+template <bool HUBER>
+#ifndef VORS_SPLIT_WAVES
+#define VORS_SPLIT_WAVES 5
+#endif
+__global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_SPLIT_WAVES))) void lm_split_eval_kernel(
+    Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
+    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int it) {
+    __shared__ LmShared s;
+    const int n_items = ws.count[it] * ws.chunks;
+    const int* list = ws.list[it & 1];
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int a = item / ws.chunks, chunk = item - a * ws.chunks;
+        const int pair = __builtin_amdgcn_readfirstlane(list[a]);
+        const LmSplitState* st = ws.state + pair;
+        const Iso model = iso_uniform(iso_load(st->phase == 0 ? st->model : st->cand));
+        ImgCtx c;
+        c.img = level_ptr(g, cur0, curu, pair, 0);
+        c.rows = g.lv[0].rows;
+        c.cols = g.lv[0].cols;
+        c.k = g.lv[0].k;
+        c.huber = g.huber_delta;
+        float acc[NACC];
+        with_level_source<true, true>(g, 0, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+            const int first = (int)((long long)n_units * chunk / ws.chunks), last = (int)((long long)n_units * (chunk + 1) / ws.chunks);
+            eval_accumulate<SPLIT_BLOCK, HUBER, false>(src, last, c, model, acc, nullptr, first);
+        });
+        block_reduce<SPLIT_BLOCK>(acc, s, 0);
+        if (threadIdx.x < NACC) ws.partials[((size_t)pair * ws.chunks + chunk) * 32 + threadIdx.x] = s.sums[0][threadIdx.x];
+        __syncthreads();
+    }
+}
+// One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
+// step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them. Pairs that continue are appended to the next list.
+__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, int it) {
+    __shared__ float red[32];
+    const int n_active = ws.count[it];
+    const int* list = ws.list[it & 1];
+    int* next = ws.list[(it + 1) & 1];
+    for (int a = blockIdx.x; a < n_active; a += gridDim.x) {
+        const int pair = list[a];
+        LmSplitState* st = ws.state + pair;
+        if (threadIdx.x < NACC) {
+            float t = 0.f;
+            for (int ch = 0; ch < ws.chunks; ++ch) t += ws.partials[((size_t)pair * ws.chunks + ch) * 32 + threadIdx.x];
+            red[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float energy = red[0] / red[1];  // energy_sum / residuals.len(): 0/0 = NaN like the reference
+            Iso cur_model = iso_load(st->model);
+            float lm_coef = st->lm_coef, cur_energy = st->cur_energy;
+            int nb_iter = st->nb_iter;
+            bool take = false, done = false;
+            if (st->phase == 0) {  // init: lm_optimizer.rs:113-118
+                take = true;
+                cur_energy = energy;
+                lm_coef = 0.1f;
+                nb_iter = 0;
+            } else {
+                const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
+                if (energy > cur_energy) {                      // Err(energy)
+                    if (too_many_iterations) done = true;
+                    else lm_coef *= 10.0f;
+                } else {
+                    const float d_energy = cur_energy - energy;
+                    take = true;
+                    cur_energy = energy;
+                    cur_model = iso_load(st->cand);
+                    if (too_many_iterations) {
+                        done = true;
+                    } else {
+                        lm_coef = 0.1f * lm_coef;
+                        if (!(d_energy > 1.0f)) done = true;
+                    }
+                }
+            }
+            if (take) {
+                for (int q = 0; q < NACC; ++q) st->sums[q] = red[q];
+                iso_store(cur_model, st->model);
+                st->cur_energy = cur_energy;
+            }
+            st->lm_coef = lm_coef;
+            if (done) {
+                st->phase = 2;
+            } else {  // step(): lm_optimizer.rs:123-136 on the kept state's sums
+                nb_iter += 1;
+                const float* sm = take ? red : st->sums;
+                float h[36], gr[6];
+                for (int q = 0; q < 6; ++q) gr[q] = sm[2 + q];
+                int k = 8;
+                for (int q = 0; q < 6; ++q)
+                    for (int r = q; r < 6; ++r) {
+                        h[q * 6 + r] = sm[k];
+                        h[r * 6 + q] = sm[k];
+                        ++k;
+                    }
+                Iso cand;
+                if (lm_step(h, gr, cur_model, lm_coef, &cand)) {
+                    iso_store(cand, st->cand);
+                    st->phase = 1;
+                    next[atomicAdd(&ws.count[it + 1], 1)] = pair;
+                } else {
+                    st->phase = 3;  // Cholesky failed: the level's progress is discarded (inverse_compositional.rs:195-199)
+                }
+            }
+            st->nb_iter = nb_iter;
+        }
+        __syncthreads();
+    }
+}
+
+#define VORS_LM_KARGS g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats
 template <int BLOCK, bool DENSE>
 static void launch_lm_track_block(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                   const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats,
-                                  int n_pairs, hipStream_t s) {
+                                  int n_pairs, int mode, LmSplitWs split, hipStream_t s) {
     if (g.huber_delta > 0.f)
-        hipLaunchKernelGGL((lm_track_kernel<BLOCK, true, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0,
-                           kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats);
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, true, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
     else
-        hipLaunchKernelGGL((lm_track_kernel<BLOCK, false, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0,
-                           kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats);
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, false, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
 }
-
-void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
-                     const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
-                     hipStream_t s) {
-    Geom g = g_in;
-    g.wide_loads_ok = (((uintptr_t)kf.level0 | (uintptr_t)kf.upper | (uintptr_t)kf_depth | (uintptr_t)rec.IZ) % 16 == 0) ? 1 : 0;
-#define VORS_LM_ARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, s
+static void launch_lm_track_mode(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                                 const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs,
+                                 int block, int mode, LmSplitWs split, hipStream_t s) {
+#define VORS_LM_ARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, mode, split, s
     if (g.mode == VORS_CANDIDATES_DENSE) {
         if (block >= 1024) launch_lm_track_block<1024, true>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, true>(VORS_LM_ARGS);
-        else launch_lm_track_block<256, true>(VORS_LM_ARGS);
+        else if (block >= 256) launch_lm_track_block<256, true>(VORS_LM_ARGS);
+        else if (block >= 128) launch_lm_track_block<128, true>(VORS_LM_ARGS);
+        else launch_lm_track_block<64, true>(VORS_LM_ARGS);
     } else {
         if (block >= 1024) launch_lm_track_block<1024, false>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, false>(VORS_LM_ARGS);
         else launch_lm_track_block<256, false>(VORS_LM_ARGS);
     }
 #undef VORS_LM_ARGS
+}
+
+void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                     const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
+                     LmSplitWs split, hipStream_t s) {
+    Geom g = g_in;
+    g.wide_loads_ok = (((uintptr_t)kf.level0 | (uintptr_t)kf.upper | (uintptr_t)kf_depth | (uintptr_t)rec.IZ) % 16 == 0) ? 1 : 0;
+#define VORS_LM_MARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block
+    if (g.mode != VORS_CANDIDATES_DENSE || split.chunks <= 0) {
+        launch_lm_track_mode(VORS_LM_MARGS, 0, split, s);
+        return;
+    }
+    // coarse levels per pair, then level 0 evaluation by evaluation, then the per-pair epilogue
+    (void)hipMemsetAsync(split.count, 0, (VORS_SPLIT_MAX_EVALS + 2) * sizeof(int), s);
+    {
+        static const int coarse_block = getenv("VORS_LM_COARSE_BLOCK") ? atoi(getenv("VORS_LM_COARSE_BLOCK")) : 0;
+        launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs,
+                             coarse_block > 0 ? coarse_block : block, 1, split, s);
+    }
+    const int full = n_pairs * split.chunks;
+    for (int it = 0; it < VORS_SPLIT_MAX_EVALS; ++it) {
+        // every pair evaluates at least twice (init + first candidate); later evaluations concern fewer and fewer pairs: smaller
+        // grids (grid-stride loops keep any count correct)
+        const int shrink = it < 3 ? 1 : (it < 6 ? 4 : 16);
+        const int grid = std::max(full / shrink, std::min(full, split.chunks * 8));
+        if (g.huber_delta > 0.f)
+            hipLaunchKernelGGL(lm_split_eval_kernel<true>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
+                               kf_depth, rec, split, it);
+        else
+            hipLaunchKernelGGL(lm_split_eval_kernel<false>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
+                               kf_depth, rec, split, it);
+        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, it);
+    }
+    launch_lm_track_mode(VORS_LM_MARGS, 2, split, s);
+#undef VORS_LM_MARGS
 }
 
 // ------------------------------------------------------------------------------------------------------------
