@@ -266,17 +266,20 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
     }
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE && !(getenv("VORS_LM_SPLIT") && atoi(getenv("VORS_LM_SPLIT")) == 0)) {
-        // evaluation-synchronous level 0 (lm_kernels.hip): chunks per pair so that large batches get ~16 workgroups per pair and
-        // small ones (down to the single tracker) still spread one evaluation over the chip; a chunk is at least 2048 pixels
-        int chunks = max_pairs >= 1024 ? 16 : (max_pairs >= 128 ? 32 : 64);
-        chunks = std::max(1, std::min(chunks, g.S0 / 2048));
-        if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(1, atoi(ev));
+        // evaluation rounds on the finest levels (lm_kernels.hip): chunks per pair so that large batches get ~16 workgroups per pair and
+        // small ones (down to the single tracker) still spread one evaluation over the chip.
+        // `chunks` = partial-sum slots per pair = the late-round cut (at least 512 pixels each); the full rounds use a quarter of it
+        int chunks = max_pairs >= 1024 ? 64 : (max_pairs >= 128 ? 128 : 256);
+        chunks = std::max(4, std::min(chunks, g.S0 / 512));
+        if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(4, atoi(ev));
         b->split.chunks = chunks;
+        b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : 2;
+        b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? 24 : 10);
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[1], np, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)VORS_SPLIT_MAX_EVALS + 2, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)VORS_SPLIT_MAX_ROUNDS + 2, &b->bytes);
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {

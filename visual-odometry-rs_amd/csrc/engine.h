@@ -64,26 +64,32 @@ struct DsoWs {
     DsoState* state;    // [1]
     int n_regions, max_stride, mask_stride;
 };
-// Evaluation-synchronous LM at level 0 (dense mode, lm_kernels.hip "split" path): the coarse levels run in the per-pair
-// kernel, then every level-0 energy evaluation is ONE launch over (active pairs x chunks of the image) followed by a tiny
-// per-pair step launch — all CUs stay busy whatever the pairs' iteration counts.
+// Evaluation rounds on the finest levels (dense mode, lm_kernels.hip "split" path): the coarse levels run in the per-pair
+// kernel; then every ROUND is one launch that evaluates the energy of each still-active pair at ITS current level and
+// candidate over (active pairs x chunks of the image), followed by a tiny per-pair launch that gives the verdict, takes the
+// next step or moves the pair to the next level. All CUs stay busy whatever the pairs' iteration counts; the few pairs still
+// iterating after `rounds` rounds finish inside the final per-pair kernel.
 struct LmSplitState {  // per pair
+    float entry[7];    // model on entry to the level: restored when step() fails (the level's progress is discarded)
     float model[7];    // kept model (the level's running estimate)
     float cand[7];     // candidate under evaluation
     float sums[32];    // sums of the kept state (energy sum, n, g[6], H upper triangle[21])
     float cur_energy, lm_coef;
     int nb_iter;
-    int phase;         // 0 init evaluation pending, 1 candidate evaluation pending, 2 level finished, 3 step() failed
-    int went_well;     // 0: a coarser level failed (the pair skips level 0)
-    int pad;
+    int lvl;           // level being solved
+    int phase;         // 0 init evaluation pending, 1 candidate evaluation pending, 2 all levels finished
+    int went_well;     // 0: a level failed (the pair skips the remaining levels)
 };
-#define VORS_SPLIT_MAX_EVALS 22  // init + at most 21 steps (nb_iter > 20 stops, lm_optimizer.rs:156-192)
+#define VORS_SPLIT_MAX_ROUNDS 30
 struct LmSplitWs {
     LmSplitState* state;  // [pairs]
     float* partials;      // [pairs][chunks][32]
-    int* list[2];         // active pair lists, ping-pong per evaluation
-    int* count;           // [VORS_SPLIT_MAX_EVALS + 2] active pairs per evaluation
-    int chunks;           // 0 = split path disabled
+    int* list[2];         // active pair lists, ping-pong per round
+    int* count;           // [VORS_SPLIT_MAX_ROUNDS + 2] active pairs per round
+    int chunks;           // partial-sum slots per pair = most chunks a pair is cut into; 0 = split path disabled
+    int chunks0;          // chunks per pair at level 0 in this launch (level l: chunks0 >> 2l), <= chunks
+    int n_split;          // levels 0 .. n_split-1 are solved this way
+    int rounds;
 };
 
 // Per-pixel inverse-depth planes of the generic-mask keyframe path (all levels).

@@ -527,20 +527,36 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
 // (inverse_compositional.rs:195-199).
 template <int BLOCK, bool HUBER, class Src>
 __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* model, int* nb_iter_out, float* energy_out,
-                            float* lm_coef_out, LmShared& s) {
+                            float* lm_coef_out, LmShared& s, const LmSplitState* resume = nullptr) {
     float acc[NACC];
     Iso cur_model = *model;
     int cur = 0;
-    eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
-    block_reduce<BLOCK>(acc, s, cur);
-    float cur_energy = uniform_f(s.sums[cur][0] / s.sums[cur][1]);  // energy_sum / residuals.len(): 0/0 = NaN like the reference
-    float lm_coef = 0.1f;
+    float cur_energy, lm_coef = 0.1f;
     int nb_iter = 0;
+    Iso cand = cur_model;
+    bool have_cand = false;
+    if (resume) {  // split path: the level was started by the chip-wide launches; a candidate is waiting for its evaluation
+        if (threadIdx.x < NACC) s.sums[0][threadIdx.x] = resume->sums[threadIdx.x];
+        __syncthreads();
+        cur_model = iso_uniform(iso_load(resume->model));
+        cand = iso_uniform(iso_load(resume->cand));
+        cur_energy = uniform_f(resume->cur_energy);
+        lm_coef = uniform_f(resume->lm_coef);
+        nb_iter = __builtin_amdgcn_readfirstlane(resume->nb_iter);
+        have_cand = true;
+    } else {
+        eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
+        block_reduce<BLOCK>(acc, s, cur);
+        cur_energy = uniform_f(s.sums[cur][0] / s.sums[cur][1]);  // energy_sum / residuals.len(): 0/0 = NaN like the reference
+    }
     for (;;) {
-        nb_iter += 1;
-        solve_step_lane0(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
-        if (uniform_f(s.cand[7]) == 0.0f) return false;
-        const Iso cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
+        if (!have_cand) {
+            nb_iter += 1;
+            solve_step_lane0(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
+            if (uniform_f(s.cand[7]) == 0.0f) return false;
+            cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
+        }
+        have_cand = false;
         eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cand, acc, nullptr);  // eval(): lm_optimizer.rs:140-149
         block_reduce<BLOCK>(acc, s, 1 - cur);
         const float energy = uniform_f(s.sums[1 - cur][0] / s.sums[1 - cur][1]);
@@ -647,7 +663,7 @@ template <int BLOCK, bool HUBER, bool DENSE>
 // Register budget: with 256-thread workgroups more resident workgroups per CU hide the latency-bound coarse levels of their
 // neighbours (measured at 4096 pairs: dense 5 waves/SIMD = 96 VGPRs +3.7 %, 6 spills; sparse 6 waves/SIMD +4 %).
 #ifndef VORS_LM_WAVES
-#define VORS_LM_WAVES (BLOCK <= 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
+#define VORS_LM_WAVES (BLOCK == 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
 #endif
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_WAVES))) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                           const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
@@ -655,8 +671,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                                                           const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
                                                           float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
                                                           vors_pair_stats* __restrict__ out_stats, int mode, LmSplitWs split) {
-    // mode 0: the whole track() of the pair. Split path (dense): mode 1 = levels L-1..1, hands the model over through
-    // split.state; mode 2 = after the level-0 launches: takes the result back, pose + keyframe test + statistics.
+    // mode 0: the whole track() of the pair. Split path (dense): mode 1 = levels L-1 .. split.n_split, hands the model over
+    // through split.state; mode 2 = after the split levels: takes the result back, pose + keyframe test + statistics.
     __shared__ LmShared s;
 #ifdef VORS_PROFILE_LEVELS
     const long long t_kernel0 = wall_clock64();
@@ -666,16 +682,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
     bool went_well = true;
-    if (mode == 2) {  // level 0 has been solved by the evaluation-synchronous launches
+    int start_lvl = g.L - 1;
+    const LmSplitState* resume = nullptr;
+    if (mode == 2) {  // the finest levels have been solved by the evaluation rounds — or are finished here (stragglers)
         const LmSplitState* st = split.state + pair;
-        lm_model = iso_uniform(iso_load(st->model));
-        went_well = st->went_well != 0 && st->phase == 2;
-        if (out_stats && threadIdx.x == 0 && st->went_well != 0) {
-            out_stats[pair].nb_iter[0] = st->phase == 2 ? st->nb_iter : 0;
-            out_stats[pair].energy[0] = st->phase == 2 ? st->cur_energy : 0.f;
+        went_well = st->went_well != 0;
+        start_lvl = -1;
+        if (went_well && st->phase < 2) {  // still iterating after the last round
+            start_lvl = st->lvl;
+            lm_model = iso_uniform(iso_load(st->entry));  // stays the result if step() fails
+            if (st->phase == 1) resume = st;
+        } else {
+            lm_model = iso_uniform(iso_load(st->model));
         }
     }
-    for (int lvl = (mode == 2 ? -1 : g.L - 1); lvl >= (mode == 1 ? 1 : 0); --lvl) {
+    for (int lvl = start_lvl; lvl >= (mode == 1 ? split.n_split : 0); --lvl) {
         ImgCtx c;
         c.img = level_ptr(g, cur0, curu, pair, lvl);
         c.rows = g.lv[lvl].rows;
@@ -690,7 +711,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const long long c_level0 = clock64();
 #endif
         with_level_source<DENSE, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
-            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s);
+            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr);
         });
         if (out_stats && threadIdx.x == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
@@ -716,6 +737,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         if (threadIdx.x == 0) {
             LmSplitState* st = split.state + pair;
             iso_store(lm_model, st->model);
+            iso_store(lm_model, st->entry);
+            st->lvl = split.n_split - 1;
             st->phase = 0;
             st->nb_iter = 0;
             st->went_well = went_well ? 1 : 0;
@@ -831,35 +854,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Split path, level 0 of dense mode: one launch per energy evaluation over (active pairs x chunks), one small launch per
-// step. Same arithmetic per point and the same control flow as solve_level; the sums are formed per chunk (fixed order:
-// thread -> wavefront -> workgroup -> chunks in index order), so results are deterministic.
+// Split path (dense mode, finest levels): one launch per energy evaluation over (active pairs x chunks), one small launch
+// per step. Same arithmetic per point and the same control flow as solve_level; the sums are formed per chunk (fixed
+// order: thread -> wavefront -> workgroup -> chunks in index order), so results are deterministic.
 // ------------------------------------------------------------------------------------------------------------
 #define SPLIT_BLOCK 256
-template <bool HUBER>
+__device__ __forceinline__ ImgCtx level_ctx(const Geom& g, const uint8_t* cur0, const uint8_t* curu, int pair, int lvl) {
+    ImgCtx c;
+    c.img = level_ptr(g, cur0, curu, pair, lvl);
+    c.rows = g.lv[lvl].rows;
+    c.cols = g.lv[lvl].cols;
+    c.k = g.lv[lvl].k;
+    c.huber = g.huber_delta;
+    return c;
+}
 #ifndef VORS_SPLIT_WAVES
 #define VORS_SPLIT_WAVES 5
 #endif
+__device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { return max(1, ws.chunks0 >> (2 * lvl)); }
+template <bool HUBER>
 __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_SPLIT_WAVES))) void lm_split_eval_kernel(
     Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
-    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int it) {
+    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round) {
     __shared__ LmShared s;
-    const int n_items = ws.count[it] * ws.chunks;
-    const int* list = ws.list[it & 1];
+    const int n_active = ws.count[round], n_items = n_active * ws.chunks0;
+    const int* list = ws.list[round & 1];
+    // item -> (chunk, pair) with the pair index fastest: the chunks a coarser level does not use are the tail of the grid, so the
+    // working workgroups stay contiguous in blockIdx (spread over all XCDs)
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int a = item / ws.chunks, chunk = item - a * ws.chunks;
+        const int chunk = item / n_active, a = item - chunk * n_active;
         const int pair = __builtin_amdgcn_readfirstlane(list[a]);
         const LmSplitState* st = ws.state + pair;
+        const int lvl = __builtin_amdgcn_readfirstlane(st->lvl);
+        const int chunks = split_chunks(ws, lvl);
+        if (chunk >= chunks) continue;  // coarser levels are cut into fewer chunks
         const Iso model = iso_uniform(iso_load(st->phase == 0 ? st->model : st->cand));
-        ImgCtx c;
-        c.img = level_ptr(g, cur0, curu, pair, 0);
-        c.rows = g.lv[0].rows;
-        c.cols = g.lv[0].cols;
-        c.k = g.lv[0].k;
-        c.huber = g.huber_delta;
+        const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
         float acc[NACC];
-        with_level_source<true, true>(g, 0, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
-            const int first = (int)((long long)n_units * chunk / ws.chunks), last = (int)((long long)n_units * (chunk + 1) / ws.chunks);
+        with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+            const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
             eval_accumulate<SPLIT_BLOCK, HUBER, false>(src, last, c, model, acc, nullptr, first);
         });
         block_reduce<SPLIT_BLOCK>(acc, s, 0);
@@ -868,18 +901,30 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
     }
 }
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
-// step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them. Pairs that continue are appended to the next list.
-__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, int it) {
+// step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
+// (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
+__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round) {
     __shared__ float red[32];
-    const int n_active = ws.count[it];
-    const int* list = ws.list[it & 1];
-    int* next = ws.list[(it + 1) & 1];
+    const int n_active = ws.count[round];
+    const int* list = ws.list[round & 1];
+    int* next = ws.list[(round + 1) & 1];
     for (int a = blockIdx.x; a < n_active; a += gridDim.x) {
         const int pair = list[a];
         LmSplitState* st = ws.state + pair;
-        if (threadIdx.x < NACC) {
+        const int lvl = st->lvl;
+        const int chunks = split_chunks(ws, lvl);
+        if (threadIdx.x < NACC) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
+            const float* pp = ws.partials + (size_t)pair * ws.chunks * 32 + threadIdx.x;
             float t = 0.f;
-            for (int ch = 0; ch < ws.chunks; ++ch) t += ws.partials[((size_t)pair * ws.chunks + ch) * 32 + threadIdx.x];
+            int ch = 0;
+            for (; ch + 8 <= chunks; ch += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = pp[(ch + q) * 32];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += v[q];
+            }
+            for (; ch < chunks; ++ch) t += pp[ch * 32];
             red[threadIdx.x] = t;
         }
         __syncthreads();
@@ -912,15 +957,29 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, int it)
                     }
                 }
             }
-            if (take) {
-                for (int q = 0; q < NACC; ++q) st->sums[q] = red[q];
+            bool again = false;
+            if (done) {  // level finished
+                if (out_stats) {
+                    out_stats[pair].nb_iter[lvl] = nb_iter;
+                    out_stats[pair].energy[lvl] = cur_energy;
+                }
                 iso_store(cur_model, st->model);
-                st->cur_energy = cur_energy;
-            }
-            st->lm_coef = lm_coef;
-            if (done) {
-                st->phase = 2;
+                if (lvl > 0) {
+                    iso_store(cur_model, st->entry);
+                    st->lvl = lvl - 1;
+                    st->phase = 0;
+                    nb_iter = 0;
+                    again = true;
+                } else {
+                    st->phase = 2;
+                }
             } else {  // step(): lm_optimizer.rs:123-136 on the kept state's sums
+                if (take) {
+                    for (int q = 0; q < NACC; ++q) st->sums[q] = red[q];
+                    iso_store(cur_model, st->model);
+                    st->cur_energy = cur_energy;
+                }
+                st->lm_coef = lm_coef;
                 nb_iter += 1;
                 const float* sm = take ? red : st->sums;
                 float h[36], gr[6];
@@ -936,12 +995,20 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, int it)
                 if (lm_step(h, gr, cur_model, lm_coef, &cand)) {
                     iso_store(cand, st->cand);
                     st->phase = 1;
-                    next[atomicAdd(&ws.count[it + 1], 1)] = pair;
-                } else {
-                    st->phase = 3;  // Cholesky failed: the level's progress is discarded (inverse_compositional.rs:195-199)
+                    again = true;
+                } else {  // Cholesky failed: the level's progress is discarded and tracking stops (inverse_compositional.rs:195-199)
+                    for (int q = 0; q < 7; ++q) st->model[q] = st->entry[q];
+                    st->went_well = 0;
+                    st->phase = 2;
+                    if (out_stats)
+                        for (int l2 = lvl; l2 >= 0; --l2) {
+                            out_stats[pair].nb_iter[l2] = 0;
+                            out_stats[pair].energy[l2] = 0.f;
+                        }
                 }
             }
             st->nb_iter = nb_iter;
+            if (again) next[atomicAdd(&ws.count[round + 1], 1)] = pair;
         }
         __syncthreads();
     }
@@ -964,9 +1031,7 @@ static void launch_lm_track_mode(const Geom& g, Pyramid cur, Pyramid kf, const u
     if (g.mode == VORS_CANDIDATES_DENSE) {
         if (block >= 1024) launch_lm_track_block<1024, true>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, true>(VORS_LM_ARGS);
-        else if (block >= 256) launch_lm_track_block<256, true>(VORS_LM_ARGS);
-        else if (block >= 128) launch_lm_track_block<128, true>(VORS_LM_ARGS);
-        else launch_lm_track_block<64, true>(VORS_LM_ARGS);
+        else launch_lm_track_block<256, true>(VORS_LM_ARGS);
     } else {
         if (block >= 1024) launch_lm_track_block<1024, false>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, false>(VORS_LM_ARGS);
@@ -985,26 +1050,29 @@ void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* 
         launch_lm_track_mode(VORS_LM_MARGS, 0, split, s);
         return;
     }
-    // coarse levels per pair, then level 0 evaluation by evaluation, then the per-pair epilogue
-    (void)hipMemsetAsync(split.count, 0, (VORS_SPLIT_MAX_EVALS + 2) * sizeof(int), s);
-    {
-        static const int coarse_block = getenv("VORS_LM_COARSE_BLOCK") ? atoi(getenv("VORS_LM_COARSE_BLOCK")) : 0;
-        launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs,
-                             coarse_block > 0 ? coarse_block : block, 1, split, s);
-    }
-    const int full = n_pairs * split.chunks;
-    for (int it = 0; it < VORS_SPLIT_MAX_EVALS; ++it) {
-        // every pair evaluates at least twice (init + first candidate); later evaluations concern fewer and fewer pairs: smaller
-        // grids (grid-stride loops keep any count correct)
-        const int shrink = it < 3 ? 1 : (it < 6 ? 4 : 16);
-        const int grid = std::max(full / shrink, std::min(full, split.chunks * 8));
+    // coarse levels per pair, then the evaluation rounds on the finest levels, then the per-pair epilogue (which also finishes
+    // the rare pairs still iterating after the last round)
+    split.n_split = std::max(1, std::min(split.n_split, g.L));
+    split.rounds = std::max(1, std::min(split.rounds, VORS_SPLIT_MAX_ROUNDS));
+    (void)hipMemsetAsync(split.count, 0, (VORS_SPLIT_MAX_ROUNDS + 2) * sizeof(int), s);
+    launch_lm_track_mode(VORS_LM_MARGS, 1, split, s);
+    const int base_chunks = std::max(1, split.chunks / 4);
+    for (int r = 0; r < split.rounds; ++r) {
+        // every pair needs at least two evaluations per level: full grids. Later rounds concern fewer and fewer pairs, finally a
+        // handful of stragglers whose evaluations are pure latency: they are cut into 4x more chunks and get small grids
+        // (grid-stride loops keep any count correct).
+        const int late = r >= 2 * split.n_split + 2;
+        split.chunks0 = late ? split.chunks : base_chunks;
+        const int full = n_pairs * split.chunks0;
+        const int shrink = r < 2 * split.n_split ? 1 : (late ? 16 : 2);
+        const int grid = std::max(std::min(full, 256), full / shrink);
         if (g.huber_delta > 0.f)
             hipLaunchKernelGGL(lm_split_eval_kernel<true>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, it);
+                               kf_depth, rec, split, r);
         else
             hipLaunchKernelGGL(lm_split_eval_kernel<false>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, it);
-        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, it);
+                               kf_depth, rec, split, r);
+        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r);
     }
     launch_lm_track_mode(VORS_LM_MARGS, 2, split, s);
 #undef VORS_LM_MARGS
