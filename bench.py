@@ -64,8 +64,8 @@ def byte_model(stats, L, rows, cols, dense):
 
 
 def lm_traffic(args):
-    """HBM bytes per lm_track_kernel launch measured with rocprofv3 PMC passes (profiles/lm_traffic.json), or None when no
-    profile of this exact workload has been committed."""
+    """HBM bytes of the LM stage of one step (all its kernels) measured with rocprofv3 PMC passes (profiles/lm_traffic.json), or
+    None when no profile of this exact workload has been committed."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "lm_traffic.json")))
     except Exception:
@@ -187,7 +187,7 @@ def main():
     dense = args.candidates == "dense"
     b_io, b_lm, evals_per_pair, ptevals_per_pair = byte_model(stats, args.levels, args.rows, args.cols, dense)
     lm_avg_s = float(lm_ms.mean()) * 1e-3
-    lm_bytes = b_lm + 32 * args.pairs  # algorithmic bytes of ONE LM-kernel launch (this rank's batch)
+    lm_bytes = b_lm + 32 * args.pairs  # algorithmic bytes of the LM stage of ONE step (this rank's batch)
     achieved = lm_bytes / lm_avg_s / 1e9
     job_gbps = (b_io + b_lm) * world * args.steps / dt / 1e9
     gt_err = np.abs(stats["lm_model"] - main_w.gt.cpu().numpy()).max(axis=1)
@@ -219,7 +219,11 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "lm_track_kernel",
+            # dense mode: the LM stage is a short sequence of launches (coarse levels per pair, then one launch per energy
+            # evaluation round on the two finest levels + a per-pair step launch, then the per-pair epilogue); it is timed as a
+            # whole with HIP events on its stream, and its algorithmic bytes are those of all its evaluations
+            "kernel": ("LM stage: lm_track_kernel (coarse levels) + lm_split_eval_kernel / lm_split_step_kernel per evaluation round "
+                       "+ lm_track_kernel (epilogue)") if dense else "lm_track_kernel",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

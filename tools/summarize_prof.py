@@ -14,7 +14,23 @@ def find(sub, pattern):
     return f[0] if f else None
 
 
+LM_STAGE = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel")
+
+
+def is_lm(name):
+    return any(k in name for k in LM_STAGE)
+
+
 stats = find("trace", "*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    split = any("lm_split_eval_kernel" in r["Name"] for r in rows)
+    track_calls = sum(int(r["Calls"]) for r in rows if "lm_track_kernel" in r["Name"])
+    steps = track_calls // 2 if split else track_calls
+    lm_total = sum(float(r["TotalDurationNs"]) for r in rows if is_lm(r["Name"]))
+    if steps:
+        lines.append(f"# LM stage ({' + '.join(k for k in LM_STAGE if any(k in r['Name'] for r in rows))}): "
+                     f"{lm_total / steps / 1e6:.3f} ms of kernel time per step over {steps} steps\n")
 if stats:
     lines.append(f"# rocprofv3 --kernel-trace --stats  ({tag})\n")
     lines.append("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|")
@@ -33,6 +49,11 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         k = r["Kernel_Name"].split("(")[0][:70]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
+    lm = [(k, n, v) for k, (n, v) in agg.items() if is_lm(k)]
+    if lm:
+        tracks = sum(n for k, n, v in lm if "lm_track_kernel" in k)
+        steps = tracks // 2 if any("lm_split_eval_kernel" in k for k, n, v in lm) else tracks
+        lines.append(f"\n# LM stage {counter}: {sum(v for k, n, v in lm) / max(steps, 1):.1f} KiB (raw counter) per step over {steps} steps")
     lines.append(f"\n# rocprofv3 --pmc {counter} (separate pass; raw counter, unit KiB per rocprof; per-launch average)\n")
     lines.append("| kernel | launches | avg per launch | total |\n|---|---|---|---|")
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -40,7 +61,8 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 for log in ("bench_trace.log",):
     p = os.path.join(out_dir, log)
     if os.path.exists(p):
-        last = open(p).read().strip().splitlines()[-1]
+        js = [l for l in open(p).read().splitlines() if l.startswith('{"metric')]
+        last = js[-1] if js else ""
         if last.startswith("{"):
             lines.append("\n# bench.py JSON line of the traced run\n\n```json\n" + last + "\n```")
 open(os.path.join(out_dir, f"summary_{tag}.md"), "w").write("\n".join(lines) + "\n")
