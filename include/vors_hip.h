@@ -114,6 +114,15 @@ vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t*
  * (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised: outputs are valid once the stream
  * reaches this point. Workspaces are allocated once at create() for up to max_pairs pairs. */
 typedef struct vors_batch vors_batch;
+/* Scheduling knobs (environment, read at create(); results stay within the stated tolerance whatever their value — they only
+ * change how the same arithmetic is spread over the chip; tests/test_gpu_parity.py covers the variants):
+ *   VORS_LM_BLOCK=256|512|1024   threads per frame pair in the per-pair LM kernel (default by batch size and mode)
+ *   VORS_LM_SPLIT=0              dense mode: one per-pair kernel for all levels instead of evaluation rounds
+ *   VORS_LM_SPLIT_LEVELS=n       dense mode: the n finest levels are solved by evaluation rounds (default 2)
+ *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before the per-pair kernel finishes the stragglers (default 24 / 10)
+ *   VORS_LM_CHUNKS=n             partial-sum chunks per pair of a level-0 evaluation (default by batch size)
+ *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
+ *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical) */
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
 vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
                                    const uint8_t* d_cur_gray, const float* d_prev_poses7 /* nullable */,
