@@ -404,6 +404,59 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
 }
+// Levels 1 AND 2 in one pass when rows(level 0) % 4 == 0 and cols(level 0) % 16 == 0 (both halvings exact, 16-byte aligned depth
+// rows): one thread per level-2 pixel reads its 4x4 depth block (four 8-byte loads), fuses the four level-1 pixels (stored:
+// inverse depth only — the level-1 weights are consumed right here and never written) and then the level-2 pixel. Halves the
+// traffic of the two largest inverse-depth passes.
+__global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
+    const int pair = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows2 = g.lv[2].rows, cols2 = g.lv[2].cols;
+    int n0 = 0, n1 = 0, n2 = 0;
+    if (t < rows2 * cols2) {
+        const int y2 = t / cols2, x2 = t - y2 * cols2;
+        const int fc = g.lv[0].cols, c1 = g.lv[1].cols;
+        const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(4 * y2) * fc + 4 * x2;
+        uint32_t w[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)r * fc);
+            w[r][0] = v.x;
+            w[r][1] = v.y;
+        }
+        float od1[2][2], ov1[2][2];  // [row][col] of the 2x2 level-1 block
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1)   (multires.rs:80-83)
+                const uint32_t top = w[2 * i][j], bot = w[2 * i + 1][j];
+                const uint32_t dz[4] = {top & 0xffffu, bot & 0xffffu, top >> 16, bot >> 16};
+                float dv[4], vv[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+                    vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
+                    n0 += dz[m] != 0;
+                }
+                fuse_dso_mean(dv, vv, &od1[i][j], &ov1[i][j]);
+                n1 += ov1[i][j] >= 0.f;
+            }
+        const size_t s1 = (size_t)pair * g.slots_total + g.lv[1].slot_off + (size_t)(2 * y2) * c1 + 2 * x2;
+        *reinterpret_cast<float2*>(rec.IZ + s1) = make_float2(od1[0][0], od1[0][1]);
+        *reinterpret_cast<float2*>(rec.IZ + s1 + c1) = make_float2(od1[1][0], od1[1][1]);
+        const float dv2[4] = {od1[0][0], od1[1][0], od1[0][1], od1[1][1]}, vv2[4] = {ov1[0][0], ov1[1][0], ov1[0][1], ov1[1][1]};
+        float od, ov;
+        fuse_dso_mean(dv2, vv2, &od, &ov);
+        const size_t s2 = (size_t)pair * g.slots_total + g.lv[2].slot_off + t;
+        rec.IZ[s2] = od;
+        rec.V[s2] = ov;
+        n2 = ov >= 0.f;
+    }
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 2, n2);
+}
 __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, Records rec) {
     const int pair = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,15 +519,20 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
     const int n_roots = g.root_rows * g.root_cols;
     if (g.mode == VORS_CANDIDATES_DENSE) {
         (void)hipMemsetAsync(rec.n_used, 0, (size_t)n_pairs * VORS_MAX_LEVELS * sizeof(int), s);
+        int next = 2;
         if (g.L >= 2) {
-            // (slots_total and slot_off are multiples of 4, so the level-1 stores of the wide kernel are 16-byte aligned)
-            const bool wide = g.lv[0].cols % 8 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0;
-            if (wide)
+            // (slots_total and slot_off are multiples of 4, so the vector stores of the wide kernels are aligned)
+            const bool aligned = reinterpret_cast<uintptr_t>(depth) % 16 == 0;
+            if (g.L >= 3 && aligned && g.lv[0].rows % 4 == 0 && g.lv[0].cols % 16 == 0) {
+                hipLaunchKernelGGL(dense_idepth_level12_kernel, dim3((g.lv[2].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                next = 3;
+            } else if (aligned && g.lv[0].cols % 8 == 0) {
                 hipLaunchKernelGGL(dense_idepth_level1_wide_kernel, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
-            else
+            } else {
                 hipLaunchKernelGGL(dense_idepth_level1_kernel, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+            }
         }
-        for (int l = 2; l < g.L; ++l)
+        for (int l = next; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {
         static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
