@@ -213,7 +213,8 @@ VORS_HD float div_uniform(float x, const FastDiv& f) {
         const float q = x * f.r;
         const float e = fmaf(-q, f.d, x);
         const float q1 = fmaf(e, f.r, q);
-        return x == 0.0f ? x * f.r : q1;  // keeps the sign of a zero quotient
+        // q already carries the sign of the true quotient (also for x = -0, where the correction term would give +0): one v_bfi
+        return __builtin_copysignf(q1, q);
     }
     return x / f.d;
 }
