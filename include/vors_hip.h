@@ -118,7 +118,7 @@ typedef struct vors_batch vors_batch;
  * change how the same arithmetic is spread over the chip; tests/test_gpu_parity.py covers the variants):
  *   VORS_LM_BLOCK=256|512|1024   threads per frame pair in the per-pair LM kernel (default by batch size and mode)
  *   VORS_LM_SPLIT=0              dense mode: one per-pair kernel for all levels instead of evaluation rounds
- *   VORS_LM_SPLIT_LEVELS=n       dense mode: the n finest levels are solved by evaluation rounds (default 2)
+ *   VORS_LM_SPLIT_LEVELS=n       dense mode: the n finest levels are solved by evaluation rounds (default: levels of >= 64 Ki pixels)
  *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before the per-pair kernel finishes the stragglers (default 24 / 10)
  *   VORS_LM_CHUNKS=n             partial-sum chunks per pair of a level-0 evaluation (default by batch size)
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)

@@ -273,7 +273,11 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         chunks = std::max(4, std::min(chunks, g.S0 / 512));
         if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(4, atoi(ev));
         b->split.chunks = chunks;
-        b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : 2;
+        // levels worth a chip-wide launch per evaluation: at least 64 Ki pixels (640x480: levels 0 and 1; 1280x960: 0, 1, 2)
+        int n_split = 0;
+        for (int l = 0; l < g.L; ++l)
+            if ((long long)g.lv[l].rows * g.lv[l].cols >= 65536) n_split = l + 1;
+        b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : std::max(1, n_split);
         b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? 24 : 10);
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
