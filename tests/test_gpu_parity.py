@@ -481,3 +481,24 @@ def test_dense_lm_scheduling_variants_vs_oracle(env, monkeypatch):
     # evaluations per level are reported by every schedule (they feed bench.py's byte model)
     assert ((stats["nb_iter"][ok][:, :L] >= 1) & (stats["nb_iter"][ok][:, :L] <= 21)).all()
     assert (stats["nb_iter"][~ok][:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_optional_outputs_and_host_buffer_entry(mode):
+    """out_stats is nullable everywhere (the kernels must not touch it) and the host-buffer entry vors_track_pairs gives the same
+    poses as the device-resident engine."""
+    import torch
+    rows, cols, L, n = 120, 160, 4, 5
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=(BLOCKY if mode == 2 else 0) | 0x5EED8800, intr=intr)
+    b, poses, status, stats, t = run_batch(vcfg(L, intr, mode), kg, kd, cg)
+    poses2 = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    status2 = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    b.track_pairs(*t, poses2, status2, None)                        # no statistics requested
+    torch.cuda.synchronize()
+    assert (poses2.cpu().numpy() == poses).all() and (status2.cpu().numpy() == status).all()
+    hp, hs, hst = V.track_pairs(vcfg(L, intr, mode), kg, kd, cg, want_stats=False)   # host buffers, no statistics
+    assert hst is None and (hp == poses).all() and (hs == status).all()
+    hp2, hs2, hst2 = V.track_pairs(vcfg(L, intr, mode), np.ascontiguousarray(kg.transpose(0, 2, 1)), np.ascontiguousarray(kd.transpose(0, 2, 1)),
+                                   np.ascontiguousarray(cg.transpose(0, 2, 1)), layout=V.COL_MAJOR)  # DMatrix layout
+    assert (hp2 == poses).all() and (hst2["n_points"][:, :L] == stats["n_points"][:, :L]).all()
