@@ -265,7 +265,7 @@ def main():
         # ---- CPU baseline: the oracle (C++ restatement of the reference, single thread like the reference)
         n_cpu = args.cpu_pairs
         if n_cpu < 0:
-            n_cpu = 16 if dense else 64
+            n_cpu = 256 if dense else 2048   # about 10 s (dense) / 5 s (sparse) of single-thread work, plus the all-cores leg
         n_cpu = min(n_cpu, args.pairs)
         if n_cpu > 0:
             from oracle import oracle as O
