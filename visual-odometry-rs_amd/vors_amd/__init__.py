@@ -15,6 +15,7 @@ raises VorsError when the library or a HIP device is missing.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -105,6 +106,13 @@ def lib():
     """Load libvors_hip.so. Import torch first when sharing device memory with it (same HIP runtime SONAME)."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime: load it FIRST so that libvors_hip.so binds to the same one (two runtimes in one process
+        # do not see each other's devices / allocations). The library itself does not depend on torch.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise VorsError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback)")
