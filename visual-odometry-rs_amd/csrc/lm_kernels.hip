@@ -672,19 +672,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                                                           float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
                                                           vors_pair_stats* __restrict__ out_stats, int mode, LmSplitWs split) {
     // mode 0: the whole track() of the pair. Split path (dense): mode 1 = levels L-1 .. split.n_split, hands the model over
-    // through split.state; mode 2 = after the split levels: takes the result back, pose + keyframe test + statistics.
+    // through split.state; mode 3 = workgroup a finishes the a-th pair still iterating after the last evaluation round (a big
+    // workgroup each, all of them in parallel); mode 2 = takes the results back: pose + keyframe test + statistics (and
+    // finishes whatever mode 3 could not take).
     __shared__ LmShared s;
 #ifdef VORS_PROFILE_LEVELS
     const long long t_kernel0 = wall_clock64();
 #endif
-    const int pair = blockIdx.x;
+    int pair = blockIdx.x;
+    if (mode == 3) {
+        if ((int)blockIdx.x >= split.count[split.rounds]) return;
+        pair = __builtin_amdgcn_readfirstlane(split.list[split.rounds & 1][blockIdx.x]);
+    }
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
     bool went_well = true;
     int start_lvl = g.L - 1;
     const LmSplitState* resume = nullptr;
-    if (mode == 2) {  // the finest levels have been solved by the evaluation rounds — or are finished here (stragglers)
+    if (mode >= 2) {  // the finest levels have been solved by the evaluation rounds — or are finished here (stragglers)
         const LmSplitState* st = split.state + pair;
         went_well = st->went_well != 0;
         start_lvl = -1;
@@ -732,6 +738,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                 }
             break;
         }
+    }
+    if (mode == 3) {  // hand the finished pair back to the bookkeeping of mode 2
+        if (threadIdx.x == 0) {
+            LmSplitState* st = split.state + pair;
+            iso_store(lm_model, st->model);
+            st->went_well = went_well ? 1 : 0;
+            st->phase = 2;
+        }
+        return;
     }
     if (mode == 1) {
         if (threadIdx.x == 0) {
@@ -1074,6 +1089,9 @@ void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* 
                                kf_depth, rec, split, r);
         hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r);
     }
+    // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
+    launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
+                         split, s);
     launch_lm_track_mode(VORS_LM_MARGS, 2, split, s);
 #undef VORS_LM_MARGS
 }
