@@ -409,26 +409,29 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
 // inverse depth only — the level-1 weights are consumed right here and never written) and then the level-2 pixel. Halves the
 // traffic of the two largest inverse-depth passes.
 __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
+    // TWO horizontally adjacent level-2 pixels per thread: 16-byte loads of the four depth rows, 16-byte stores of the two level-1 rows
     const int pair = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int rows2 = g.lv[2].rows, cols2 = g.lv[2].cols;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int rows2 = g.lv[2].rows, cols2 = g.lv[2].cols;  // cols2 is a multiple of 4 here
     int n0 = 0, n1 = 0, n2 = 0;
     if (t < rows2 * cols2) {
         const int y2 = t / cols2, x2 = t - y2 * cols2;
         const int fc = g.lv[0].cols, c1 = g.lv[1].cols;
         const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(4 * y2) * fc + 4 * x2;
-        uint32_t w[4][2];
+        uint32_t w[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)r * fc);
+            const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)r * fc);
             w[r][0] = v.x;
             w[r][1] = v.y;
+            w[r][2] = v.z;
+            w[r][3] = v.w;
         }
-        float od1[2][2], ov1[2][2];  // [row][col] of the 2x2 level-1 block
+        float od1[2][4], ov1[2][4];  // [row][col] of the 2x4 level-1 block
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1)   (multires.rs:80-83)
                 const uint32_t top = w[2 * i][j], bot = w[2 * i + 1][j];
                 const uint32_t dz[4] = {top & 0xffffu, bot & 0xffffu, top >> 16, bot >> 16};
@@ -443,15 +446,19 @@ __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const
                 n1 += ov1[i][j] >= 0.f;
             }
         const size_t s1 = (size_t)pair * g.slots_total + g.lv[1].slot_off + (size_t)(2 * y2) * c1 + 2 * x2;
-        *reinterpret_cast<float2*>(rec.IZ + s1) = make_float2(od1[0][0], od1[0][1]);
-        *reinterpret_cast<float2*>(rec.IZ + s1 + c1) = make_float2(od1[1][0], od1[1][1]);
-        const float dv2[4] = {od1[0][0], od1[1][0], od1[0][1], od1[1][1]}, vv2[4] = {ov1[0][0], ov1[1][0], ov1[0][1], ov1[1][1]};
-        float od, ov;
-        fuse_dso_mean(dv2, vv2, &od, &ov);
+        *reinterpret_cast<float4*>(rec.IZ + s1) = make_float4(od1[0][0], od1[0][1], od1[0][2], od1[0][3]);
+        *reinterpret_cast<float4*>(rec.IZ + s1 + c1) = make_float4(od1[1][0], od1[1][1], od1[1][2], od1[1][3]);
+        float od[2], ov[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float dv2[4] = {od1[0][2 * k], od1[1][2 * k], od1[0][2 * k + 1], od1[1][2 * k + 1]};
+            const float vv2[4] = {ov1[0][2 * k], ov1[1][2 * k], ov1[0][2 * k + 1], ov1[1][2 * k + 1]};
+            fuse_dso_mean(dv2, vv2, &od[k], &ov[k]);
+            n2 += ov[k] >= 0.f;
+        }
         const size_t s2 = (size_t)pair * g.slots_total + g.lv[2].slot_off + t;
-        rec.IZ[s2] = od;
-        rec.V[s2] = ov;
-        n2 = ov >= 0.f;
+        *reinterpret_cast<float2*>(rec.IZ + s2) = make_float2(od[0], od[1]);
+        *reinterpret_cast<float2*>(rec.V + s2) = make_float2(ov[0], ov[1]);
     }
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
@@ -524,7 +531,7 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
             // (slots_total and slot_off are multiples of 4, so the vector stores of the wide kernels are aligned)
             const bool aligned = reinterpret_cast<uintptr_t>(depth) % 16 == 0;
             if (g.L >= 3 && aligned && g.lv[0].rows % 4 == 0 && g.lv[0].cols % 16 == 0) {
-                hipLaunchKernelGGL(dense_idepth_level12_kernel, dim3((g.lv[2].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                hipLaunchKernelGGL(dense_idepth_level12_kernel, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
                 next = 3;
             } else if (aligned && g.lv[0].cols % 8 == 0) {
                 hipLaunchKernelGGL(dense_idepth_level1_wide_kernel, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
