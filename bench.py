@@ -63,25 +63,6 @@ def byte_model(stats, L, rows, cols, dense):
     return b_io, b_lm, float(evals.sum(1).mean()), float((evals * n_pts).sum(1).mean())
 
 
-VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12  # lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes per clock (a wave64 f32 instruction
-                                                # issues in 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz = 78.6 T = 157 TFLOP/s of FMAs
-
-
-def valu_model(stats, L, rows, cols):
-    """Dense mode only: VALU lane-instructions the LM stage executes per step, from the evaluations the kernels report and the
-    instruction count of the evaluation loop body in the ISA of this build (hipcc -S: 895 per quad of 4 pixels at level 0,
-    1000 at levels >= 1; the profile in profiles/r01_dense_lm_sq_counters.md confirms the executed count within 2 %)."""
-    nb_iter = stats["nb_iter"][:, :L].astype(np.int64)
-    evals = np.where(nb_iter > 0, nb_iter + 1, 0)
-    lane_instr = 0
-    r, c = rows, cols
-    for l in range(L):
-        quads = r * ((c + 3) // 4)
-        lane_instr += int(evals[:, l].sum()) * quads * (895 if l == 0 else 1000)
-        r, c = r // 2, c // 2
-    return lane_instr
-
-
 def lm_traffic(args):
     """HBM bytes of the LM stage of one step (all its kernels) measured with rocprofv3 PMC passes (profiles/lm_traffic.json), or
     None when no profile of this exact workload has been committed."""
@@ -262,12 +243,6 @@ def main():
         "pose_err_vs_ground_truth": {"median": float(np.median(gt_err)), "max": float(gt_err.max())},
     }
 
-    if dense and (args.cols % 4 == 0):
-        # What actually bounds the dense LM stage: vector-ALU instruction issue, not HBM. Reported beside
-        # the contract's HBM roofline; "achieved" counts the instructions of the evaluation loops only.
-        li = valu_model(stats, args.levels, args.rows, args.cols)
-        out["roofline"]["valu_issue"] = {"achieved": round(li / lm_avg_s / 1e12, 2), "peak": round(VALU_PEAK_TLANE, 1),
-                                         "unit": "T lane-instructions/s", "frac": round(li / lm_avg_s / 1e12 / VALU_PEAK_TLANE, 4)}
     if rank == 0 and world == 1:
         # ---- secondary measurement: the other candidate mode (reference selection when the headline is dense)
         if not args.no_secondary and args.candidates != "dso":

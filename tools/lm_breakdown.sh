@@ -6,7 +6,7 @@ f=glob.glob("gpurun_out/d1/trace/**/*kernel_trace.csv",recursive=True)[0]
 rows=sorted(csv.DictReader(open(f)),key=lambda r:int(r["Start_Timestamp"]))
 # last step: from the last mode-1 lm_track launch to the end
 idx=[i for i,r in enumerate(rows) if "lm_track_kernel" in r["Kernel_Name"]]
-start=idx[-2]
+start=idx[-3]
 t0=int(rows[start]["Start_Timestamp"])
 for r in rows[start:]:
     n=r["Kernel_Name"]; n=n[n.find("vors::")+6:][:34]

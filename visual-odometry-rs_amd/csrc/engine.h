@@ -77,10 +77,11 @@ struct LmSplitState {  // per pair
     float cur_energy, lm_coef;
     int nb_iter;
     int lvl;           // level being solved
-    int phase;         // 0 init evaluation pending, 1 candidate evaluation pending, 2 all levels finished
+    int phase;         // 0 init evaluation pending (full), 1 candidate's energy pending, 4 accepted candidate's g and H pending (full),
+                       // 2 all levels finished
     int went_well;     // 0: a level failed (the pair skips the remaining levels)
 };
-#define VORS_SPLIT_MAX_ROUNDS 30
+#define VORS_SPLIT_MAX_ROUNDS 62
 struct LmSplitWs {
     LmSplitState* state;  // [pairs]
     float* partials;      // [pairs][chunks][32]

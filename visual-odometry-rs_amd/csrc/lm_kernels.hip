@@ -343,7 +343,8 @@ __device__ __forceinline__ Taps load_taps(const ImgCtx& c, const Warped& w) {
     return Taps{a, b};
 }
 // bilinear (lm_optimizer.rs:236-247, term order as written) + residual + the 29 sums. Returns the residual (NaN if outside).
-template <bool HUBER>
+// ENERGY_ONLY: eval_energy alone (lm_optimizer.rs:68-87) — the sums 0 and 1; the Jacobian is not touched.
+template <bool HUBER, bool ENERGY_ONLY = false>
 __device__ __forceinline__ float accumulate_point(const ImgCtx& c, float tmpl, const float J[6], const Warped& w, const Taps& t,
                                                   float acc[NACC]) {
     const float vu_00 = (float)(t.top & 0xff), vu_01 = (float)(t.top >> 8), vu_10 = (float)(t.bot & 0xff), vu_11 = (float)(t.bot >> 8);
@@ -352,6 +353,16 @@ __device__ __forceinline__ float accumulate_point(const ImgCtx& c, float tmpl, c
     const float r_true = im - tmpl;
     // Outside / empty points contribute exactly nothing: selected to zero (never multiplied: 0 * inf would poison the sums).
     const float r = w.inside ? r_true : 0.f;
+    if (ENERGY_ONLY) {
+        if (HUBER) {
+            const float ar = fabsf(r);
+            acc[0] += ar > c.huber ? c.huber * (2.0f * ar - c.huber) : r * r;
+        } else {
+            acc[0] = fmaf(r, r, acc[0]);
+        }
+        acc[1] += w.inside ? 1.0f : 0.f;
+        return w.inside ? r_true : __builtin_nanf("");
+    }
     float Jm[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) Jm[q] = w.inside ? J[q] : 0.f;
@@ -389,7 +400,7 @@ __device__ __forceinline__ Iso iso_uniform(const Iso& m) {
 
 // The per-group body shared by both loop shapes: warp all G points, issue all taps, then Jacobians + sums two points at a
 // time (keeps the live Jacobian registers at 12 while the tap loads are in flight).
-template <bool HUBER, bool WRITE_RES, class Src>
+template <bool HUBER, bool WRITE_RES, bool ENERGY_ONLY, class Src>
 __device__ __forceinline__ void process_group(const Src& src, const typename Src::Raw& raw, int n_units, const ImgCtx& c,
                                               const Iso& model, float acc[NACC], float* residuals) {
     constexpr int G = Src::G;
@@ -412,12 +423,12 @@ __device__ __forceinline__ void process_group(const Src& src, const typename Src
         float J[2][6];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            if (g0 + h < G) src.jacobian(raw, g0 + h, J[h]);  // independent of the taps: overlaps their latency
+            if (!ENERGY_ONLY && g0 + h < G) src.jacobian(raw, g0 + h, J[h]);  // independent of the taps: overlaps their latency
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             if (g0 + h < G) {
                 const int g = g0 + h;
-                const float res = accumulate_point<HUBER>(c, pos[g].tmpl, J[h], w[g], t[g], acc);
+                const float res = accumulate_point<HUBER, ENERGY_ONLY>(c, pos[g].tmpl, J[h], w[g], t[g], acc);
                 if (WRITE_RES) {
                     const int sl = src.slot(raw, g, n_units);
                     if (sl >= 0) residuals[sl] = res;
@@ -429,7 +440,7 @@ __device__ __forceinline__ void process_group(const Src& src, const typename Src
 // One evaluation sweep over the units of a level: each thread accumulates its strided share, Src::G points in flight.
 // Sources with PREFETCH keep the raw words of the NEXT unit in flight while the current one is processed, so the wavefronts
 // of a SIMD do not all stall on the same loads at the top of every iteration.
-template <int BLOCK, bool HUBER, bool WRITE_RES, class Src>
+template <int BLOCK, bool HUBER, bool WRITE_RES, class Src, bool ENERGY_ONLY = false>
 __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, const ImgCtx& c, const Iso& model, float acc[NACC],
                                                 float* residuals, int first = 0) {
 #pragma unroll
@@ -446,7 +457,7 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
             if (more) src.load(nxt, ld_next);
             typename Src::Raw raw;
             src.decode(ld, raw);
-            process_group<HUBER, WRITE_RES>(src, raw, n_units, c, model, acc, residuals);
+            process_group<HUBER, WRITE_RES, ENERGY_ONLY>(src, raw, n_units, c, model, acc, residuals);
             if (!more) break;
             ld = ld_next;
             cur = nxt;
@@ -455,7 +466,7 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
         for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
             typename Src::Raw raw;
             src.template fetch<BLOCK>(cur, n_units, raw);
-            process_group<HUBER, WRITE_RES>(src, raw, n_units, c, model, acc, residuals);
+            process_group<HUBER, WRITE_RES, ENERGY_ONLY>(src, raw, n_units, c, model, acc, residuals);
         }
     }
 }
@@ -544,6 +555,11 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
         lm_coef = uniform_f(resume->lm_coef);
         nb_iter = __builtin_amdgcn_readfirstlane(resume->nb_iter);
         have_cand = true;
+        if (__builtin_amdgcn_readfirstlane(resume->phase) == 4) {  // the kept model is an accepted candidate whose g, H are due
+            eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);
+            block_reduce<BLOCK>(acc, s, cur);
+            have_cand = false;
+        }
     } else {
         eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
         block_reduce<BLOCK>(acc, s, cur);
@@ -694,10 +710,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const LmSplitState* st = split.state + pair;
         went_well = st->went_well != 0;
         start_lvl = -1;
-        if (went_well && st->phase < 2) {  // still iterating after the last round
+        if (went_well && st->phase != 2) {  // still iterating after the last round
             start_lvl = st->lvl;
             lm_model = iso_uniform(iso_load(st->entry));  // stays the result if step() fails
-            if (st->phase == 1) resume = st;
+            if (st->phase == 1 || st->phase == 4) resume = st;
         } else {
             lm_model = iso_uniform(iso_load(st->model));
         }
@@ -903,15 +919,35 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
         const int lvl = __builtin_amdgcn_readfirstlane(st->lvl);
         const int chunks = split_chunks(ws, lvl);
         if (chunk >= chunks) continue;  // coarser levels are cut into fewer chunks
-        const Iso model = iso_uniform(iso_load(st->phase == 0 ? st->model : st->cand));
+        // A candidate is first evaluated for its energy alone (eval_energy, lm_optimizer.rs:68-87: ~35 % fewer instructions per
+        // point); g and H (compute_eval_data, :90-107) are formed in a later round only if the candidate is accepted AND the
+        // level goes on — like the reference's `eval`, which never builds them for a rejected candidate. The init evaluation
+        // (phase 0) and that later round (phase 4) are full evaluations at the kept model.
+        const int phase = __builtin_amdgcn_readfirstlane(st->phase);
+        const Iso model = iso_uniform(iso_load(phase == 1 ? st->cand : st->model));
         const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
         float acc[NACC];
-        with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
-            const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
-            eval_accumulate<SPLIT_BLOCK, HUBER, false>(src, last, c, model, acc, nullptr, first);
-        });
-        block_reduce<SPLIT_BLOCK>(acc, s, 0);
-        if (threadIdx.x < NACC) ws.partials[((size_t)pair * ws.chunks + chunk) * 32 + threadIdx.x] = s.sums[0][threadIdx.x];
+        float* out = ws.partials + ((size_t)pair * ws.chunks + chunk) * 32;
+        if (phase == 1) {
+            with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+                const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
+                eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, true>(
+                    src, last, c, model, acc, nullptr, first);
+            });
+            float e = acc[0], cnt = acc[1];
+            block_sum2<SPLIT_BLOCK>(e, cnt, s);
+            if (threadIdx.x == 0) {
+                out[0] = e;
+                out[1] = cnt;
+            }
+        } else {
+            with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+                const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
+                eval_accumulate<SPLIT_BLOCK, HUBER, false>(src, last, c, model, acc, nullptr, first);
+            });
+            block_reduce<SPLIT_BLOCK>(acc, s, 0);
+            if (threadIdx.x < NACC) out[threadIdx.x] = s.sums[0][threadIdx.x];
+        }
         __syncthreads();
     }
 }
@@ -928,7 +964,9 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
         LmSplitState* st = ws.state + pair;
         const int lvl = st->lvl;
         const int chunks = split_chunks(ws, lvl);
-        if (threadIdx.x < NACC) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
+        const int phase = st->phase;
+        const int n_sums = phase == 1 ? 2 : NACC;  // an energy-only round wrote the first two sums only
+        if (threadIdx.x < n_sums) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
             const float* pp = ws.partials + (size_t)pair * ws.chunks * 32 + threadIdx.x;
             float t = 0.f;
             int ch = 0;
@@ -948,12 +986,14 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
             Iso cur_model = iso_load(st->model);
             float lm_coef = st->lm_coef, cur_energy = st->cur_energy;
             int nb_iter = st->nb_iter;
-            bool take = false, done = false;
-            if (st->phase == 0) {  // init: lm_optimizer.rs:113-118
+            bool take = false, done = false, need_gh = false;
+            if (phase == 0) {  // init: lm_optimizer.rs:113-118
                 take = true;
                 cur_energy = energy;
                 lm_coef = 0.1f;
                 nb_iter = 0;
+            } else if (phase == 4) {  // g, H of the candidate accepted one round ago (now the kept model): on to its step()
+                take = true;
             } else {
                 const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
                 if (energy > cur_energy) {                      // Err(energy)
@@ -961,7 +1001,6 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     else lm_coef *= 10.0f;
                 } else {
                     const float d_energy = cur_energy - energy;
-                    take = true;
                     cur_energy = energy;
                     cur_model = iso_load(st->cand);
                     if (too_many_iterations) {
@@ -969,6 +1008,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     } else {
                         lm_coef = 0.1f * lm_coef;
                         if (!(d_energy > 1.0f)) done = true;
+                        else need_gh = true;  // the level goes on from this candidate: its g and H are needed
                     }
                 }
             }
@@ -988,10 +1028,15 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                 } else {
                     st->phase = 2;
                 }
+            } else if (need_gh) {
+                iso_store(cur_model, st->model);
+                st->cur_energy = cur_energy;
+                st->lm_coef = lm_coef;
+                st->phase = 4;
+                again = true;
             } else {  // step(): lm_optimizer.rs:123-136 on the kept state's sums
                 if (take) {
                     for (int q = 0; q < NACC; ++q) st->sums[q] = red[q];
-                    iso_store(cur_model, st->model);
                     st->cur_energy = cur_energy;
                 }
                 st->lm_coef = lm_coef;
