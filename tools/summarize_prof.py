@@ -15,6 +15,7 @@ def find(sub, pattern):
 
 
 LM_STAGE = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel")
+ONCE_PER_STEP = ("dense_idepth_level1", "keyframe_sparse_kernel", "dso_rounds_kernel")  # kernels launched exactly once per bench step
 
 
 def is_lm(name):
@@ -24,9 +25,8 @@ def is_lm(name):
 stats = find("trace", "*kernel_stats.csv")
 if stats:
     rows = list(csv.DictReader(open(stats)))
-    split = any("lm_split_eval_kernel" in r["Name"] for r in rows)
-    track_calls = sum(int(r["Calls"]) for r in rows if "lm_track_kernel" in r["Name"])
-    steps = track_calls // 2 if split else track_calls
+    once = [int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ONCE_PER_STEP)]
+    steps = max(once) if once else 0
     lm_total = sum(float(r["TotalDurationNs"]) for r in rows if is_lm(r["Name"]))
     if steps:
         lines.append(f"# LM stage ({' + '.join(k for k in LM_STAGE if any(k in r['Name'] for r in rows))}): "
@@ -51,8 +51,8 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         agg[k][1] += float(r["Counter_Value"])
     lm = [(k, n, v) for k, (n, v) in agg.items() if is_lm(k)]
     if lm:
-        tracks = sum(n for k, n, v in lm if "lm_track_kernel" in k)
-        steps = tracks // 2 if any("lm_split_eval_kernel" in k for k, n, v in lm) else tracks
+        once = [n for k, (n, v) in agg.items() if any(o in k for o in ONCE_PER_STEP)]
+        steps = max(once) if once else 0
         lines.append(f"\n# LM stage {counter}: {sum(v for k, n, v in lm) / max(steps, 1):.1f} KiB (raw counter) per step over {steps} steps")
     lines.append(f"\n# rocprofv3 --pmc {counter} (separate pass; raw counter, unit KiB per rocprof; per-launch average)\n")
     lines.append("| kernel | launches | avg per launch | total |\n|---|---|---|---|")
