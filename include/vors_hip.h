@@ -119,7 +119,7 @@ typedef struct vors_batch vors_batch;
  *   VORS_LM_BLOCK=256|512|1024   threads per frame pair in the per-pair LM kernel (default by batch size and mode)
  *   VORS_LM_SPLIT=0              dense mode: one per-pair kernel for all levels instead of evaluation rounds
  *   VORS_LM_SPLIT_LEVELS=n       dense mode: the n finest levels are solved by evaluation rounds (default: levels of >= 64 Ki pixels)
- *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before per-pair workgroups finish the stragglers (default 36 / 20 / 10 by batch size)
+ *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before per-pair workgroups finish the stragglers (default 26 / 16 / 10 by batch size)
  *   VORS_LM_CHUNKS=n             partial-sum chunks per pair of a level-0 evaluation (default by batch size)
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
  *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical) */

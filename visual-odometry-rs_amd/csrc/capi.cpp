@@ -278,7 +278,7 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         for (int l = 0; l < g.L; ++l)
             if ((long long)g.lv[l].rows * g.lv[l].cols >= 65536) n_split = l + 1;
         b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : std::max(1, n_split);
-        b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? 36 : (max_pairs >= 100 ? 20 : 10));
+        b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? 26 : (max_pairs >= 100 ? 16 : 10));
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);

@@ -906,7 +906,7 @@ __device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { retu
 template <bool HUBER>
 __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_SPLIT_WAVES))) void lm_split_eval_kernel(
     Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
-    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round) {
+    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round, int late) {
     __shared__ LmShared s;
     const int n_active = ws.count[round], n_items = n_active * ws.chunks0;
     const int* list = ws.list[round & 1];
@@ -922,13 +922,14 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
         // A candidate is first evaluated for its energy alone (eval_energy, lm_optimizer.rs:68-87: ~35 % fewer instructions per
         // point); g and H (compute_eval_data, :90-107) are formed in a later round only if the candidate is accepted AND the
         // level goes on — like the reference's `eval`, which never builds them for a rejected candidate. The init evaluation
-        // (phase 0) and that later round (phase 4) are full evaluations at the kept model.
+        // (phase 0) and that later round (phase 4) are full evaluations at the kept model. In the late rounds (a handful of
+        // stragglers, the chip idle) candidates get the full evaluation at once: fewer rounds for the same result.
         const int phase = __builtin_amdgcn_readfirstlane(st->phase);
         const Iso model = iso_uniform(iso_load(phase == 1 ? st->cand : st->model));
         const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
         float acc[NACC];
         float* out = ws.partials + ((size_t)pair * ws.chunks + chunk) * 32;
-        if (phase == 1) {
+        if (phase == 1 && !late) {
             with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
                 const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
                 eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, true>(
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
 // step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
 // (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
-__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round) {
+__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late) {
     __shared__ float red[32];
     const int n_active = ws.count[round];
     const int* list = ws.list[round & 1];
@@ -965,7 +966,8 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
         const int lvl = st->lvl;
         const int chunks = split_chunks(ws, lvl);
         const int phase = st->phase;
-        const int n_sums = phase == 1 ? 2 : NACC;  // an energy-only round wrote the first two sums only
+        const bool have_full = phase != 1 || late;  // an energy-only round wrote the first two sums only
+        const int n_sums = have_full ? NACC : 2;
         if (threadIdx.x < n_sums) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
             const float* pp = ws.partials + (size_t)pair * ws.chunks * 32 + threadIdx.x;
             float t = 0.f;
@@ -1008,7 +1010,8 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     } else {
                         lm_coef = 0.1f * lm_coef;
                         if (!(d_energy > 1.0f)) done = true;
-                        else need_gh = true;  // the level goes on from this candidate: its g and H are needed
+                        else if (have_full) take = true;  // the level goes on from this candidate, its g and H are at hand
+                        else need_gh = true;              // ... or are the business of the next round
                     }
                 }
             }
@@ -1037,6 +1040,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
             } else {  // step(): lm_optimizer.rs:123-136 on the kept state's sums
                 if (take) {
                     for (int q = 0; q < NACC; ++q) st->sums[q] = red[q];
+                    iso_store(cur_model, st->model);
                     st->cur_energy = cur_energy;
                 }
                 st->lm_coef = lm_coef;
@@ -1128,11 +1132,11 @@ void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* 
         const int grid = std::max(std::min(full, 256), full / shrink);
         if (g.huber_delta > 0.f)
             hipLaunchKernelGGL(lm_split_eval_kernel<true>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, r);
+                               kf_depth, rec, split, r, late);
         else
             hipLaunchKernelGGL(lm_split_eval_kernel<false>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, r);
-        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r);
+                               kf_depth, rec, split, r, late);
+        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r, late);
     }
     // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
     launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
