@@ -283,7 +283,8 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[1], np, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)VORS_SPLIT_MAX_ROUNDS + 2, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)2 * (VORS_SPLIT_MAX_ROUNDS + 2), &b->bytes);
+        b->split.cap = max_pairs;
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {

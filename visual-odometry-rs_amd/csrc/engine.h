@@ -85,8 +85,11 @@ struct LmSplitState {  // per pair
 struct LmSplitWs {
     LmSplitState* state;  // [pairs]
     float* partials;      // [pairs][chunks][32]
-    int* list[2];         // active pair lists, ping-pong per round
-    int* count;           // [VORS_SPLIT_MAX_ROUNDS + 2] active pairs per round
+    // Active pairs of a round, ping-pong per round. One array holds both kinds: pairs due a FULL evaluation (energy, g, H) fill it
+    // from the front, pairs due an ENERGY-only evaluation of a candidate from the back — each kind has its own launch.
+    int* list[2];         // [cap]
+    int* count;           // [2][VORS_SPLIT_MAX_ROUNDS + 2]: full-kind / energy-kind pairs per round
+    int cap;              // capacity of a list = pairs of the handle
     int chunks;           // partial-sum slots per pair = most chunks a pair is cut into; 0 = split path disabled
     int chunks0;          // chunks per pair at level 0 in this launch (level l: chunks0 >> 2l), <= chunks
     int n_split;          // levels 0 .. n_split-1 are solved this way

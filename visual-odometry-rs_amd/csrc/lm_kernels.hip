@@ -618,6 +618,19 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, LmShared& s) {
     b = tb;
 }
 
+// ---- split path bookkeeping (see engine.h, LmSplitWs)
+#define SPLIT_COUNT_STRIDE (VORS_SPLIT_MAX_ROUNDS + 2)
+// a-th active pair of a round: the full-kind pairs first (front of the array), then the energy-kind ones (back of the array)
+__device__ __forceinline__ int split_active(const LmSplitWs& ws, int round, int a) {
+    const int nf = ws.count[round];
+    return a < nf ? ws.list[round & 1][a] : ws.list[round & 1][ws.cap - 1 - (a - nf)];
+}
+__device__ __forceinline__ int split_n_active(const LmSplitWs& ws, int round) { return ws.count[round] + ws.count[SPLIT_COUNT_STRIDE + round]; }
+__device__ __forceinline__ void split_append(const LmSplitWs& ws, int round, bool energy_kind, int pair) {
+    if (energy_kind) ws.list[round & 1][ws.cap - 1 - atomicAdd(&ws.count[SPLIT_COUNT_STRIDE + round], 1)] = pair;
+    else ws.list[round & 1][atomicAdd(&ws.count[round], 1)] = pair;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
 // ------------------------------------------------------------------------------------------------------------
@@ -697,8 +710,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
 #endif
     int pair = blockIdx.x;
     if (mode == 3) {
-        if ((int)blockIdx.x >= split.count[split.rounds]) return;
-        pair = __builtin_amdgcn_readfirstlane(split.list[split.rounds & 1][blockIdx.x]);
+        if ((int)blockIdx.x >= split_n_active(split, split.rounds)) return;
+        pair = __builtin_amdgcn_readfirstlane(split_active(split, split.rounds, blockIdx.x));
     }
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             st->phase = 0;
             st->nb_iter = 0;
             st->went_well = went_well ? 1 : 0;
-            if (went_well) split.list[0][atomicAdd(&split.count[0], 1)] = pair;
+            if (went_well) split_append(split, 0, false, pair);
         }
         return;
     }
@@ -903,38 +916,43 @@ __device__ __forceinline__ ImgCtx level_ctx(const Geom& g, const uint8_t* cur0, 
 #define VORS_SPLIT_WAVES 5
 #endif
 __device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { return max(1, ws.chunks0 >> (2 * lvl)); }
-template <bool HUBER>
-__global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_SPLIT_WAVES))) void lm_split_eval_kernel(
-    Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
-    const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round, int late) {
+
+#ifndef VORS_SPLIT_ENERGY_WAVES
+#define VORS_SPLIT_ENERGY_WAVES 8
+#endif
+// ENERGY = false: full evaluation (energy, g, H) of the pairs at the front of the round's list, at their kept model (init of a
+// level, or the g / H of an accepted candidate) or — late rounds — at their candidate. ENERGY = true: a candidate's energy alone
+// (eval_energy, lm_optimizer.rs:68-87: a third fewer instructions per point and a third of the registers, hence its own
+// launch at a higher occupancy) for the pairs at the back of the list; g and H (compute_eval_data, :90-107) follow in a later
+// round only if the candidate is accepted AND the level goes on — like the reference's `eval`, which never builds them for a
+// rejected candidate.
+template <bool HUBER, bool ENERGY>
+__global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(ENERGY ? VORS_SPLIT_ENERGY_WAVES : VORS_SPLIT_WAVES))) void
+lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
+                     const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round) {
     __shared__ LmShared s;
-    const int n_active = ws.count[round], n_items = n_active * ws.chunks0;
+    const int n_active = ws.count[(ENERGY ? SPLIT_COUNT_STRIDE : 0) + round], n_items = n_active * ws.chunks0;
     const int* list = ws.list[round & 1];
     // item -> (chunk, pair) with the pair index fastest: the chunks a coarser level does not use are the tail of the grid, so the
     // working workgroups stay contiguous in blockIdx (spread over all XCDs)
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int chunk = item / n_active, a = item - chunk * n_active;
-        const int pair = __builtin_amdgcn_readfirstlane(list[a]);
+        const int pair = __builtin_amdgcn_readfirstlane(ENERGY ? list[ws.cap - 1 - a] : list[a]);
         const LmSplitState* st = ws.state + pair;
         const int lvl = __builtin_amdgcn_readfirstlane(st->lvl);
         const int chunks = split_chunks(ws, lvl);
         if (chunk >= chunks) continue;  // coarser levels are cut into fewer chunks
-        // A candidate is first evaluated for its energy alone (eval_energy, lm_optimizer.rs:68-87: ~35 % fewer instructions per
-        // point); g and H (compute_eval_data, :90-107) are formed in a later round only if the candidate is accepted AND the
-        // level goes on — like the reference's `eval`, which never builds them for a rejected candidate. The init evaluation
-        // (phase 0) and that later round (phase 4) are full evaluations at the kept model. In the late rounds (a handful of
-        // stragglers, the chip idle) candidates get the full evaluation at once: fewer rounds for the same result.
         const int phase = __builtin_amdgcn_readfirstlane(st->phase);
         const Iso model = iso_uniform(iso_load(phase == 1 ? st->cand : st->model));
         const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
         float acc[NACC];
         float* out = ws.partials + ((size_t)pair * ws.chunks + chunk) * 32;
-        if (phase == 1 && !late) {
-            with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
-                const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
-                eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, true>(
-                    src, last, c, model, acc, nullptr, first);
-            });
+        with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+            const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
+            eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, ENERGY>(
+                src, last, c, model, acc, nullptr, first);
+        });
+        if (ENERGY) {
             float e = acc[0], cnt = acc[1];
             block_sum2<SPLIT_BLOCK>(e, cnt, s);
             if (threadIdx.x == 0) {
@@ -942,10 +960,6 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
                 out[1] = cnt;
             }
         } else {
-            with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
-                const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
-                eval_accumulate<SPLIT_BLOCK, HUBER, false>(src, last, c, model, acc, nullptr, first);
-            });
             block_reduce<SPLIT_BLOCK>(acc, s, 0);
             if (threadIdx.x < NACC) out[threadIdx.x] = s.sums[0][threadIdx.x];
         }
@@ -955,13 +969,12 @@ __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(VOR
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
 // step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
 // (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
-__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late) {
+__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
+                                                           int next_late) {
     __shared__ float red[32];
-    const int n_active = ws.count[round];
-    const int* list = ws.list[round & 1];
-    int* next = ws.list[(round + 1) & 1];
+    const int n_active = split_n_active(ws, round);
     for (int a = blockIdx.x; a < n_active; a += gridDim.x) {
-        const int pair = list[a];
+        const int pair = split_active(ws, round, a);
         LmSplitState* st = ws.state + pair;
         const int lvl = st->lvl;
         const int chunks = split_chunks(ws, lvl);
@@ -1072,7 +1085,8 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                 }
             }
             st->nb_iter = nb_iter;
-            if (again) next[atomicAdd(&ws.count[round + 1], 1)] = pair;
+            // a candidate goes to the energy-only launch of the next round, unless that round is a late one (full evaluations only)
+            if (again) split_append(ws, round + 1, st->phase == 1 && !next_late, pair);
         }
         __syncthreads();
     }
@@ -1118,25 +1132,33 @@ void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* 
     // the rare pairs still iterating after the last round)
     split.n_split = std::max(1, std::min(split.n_split, g.L));
     split.rounds = std::max(1, std::min(split.rounds, VORS_SPLIT_MAX_ROUNDS));
-    (void)hipMemsetAsync(split.count, 0, (VORS_SPLIT_MAX_ROUNDS + 2) * sizeof(int), s);
+    (void)hipMemsetAsync(split.count, 0, 2 * (VORS_SPLIT_MAX_ROUNDS + 2) * sizeof(int), s);
     launch_lm_track_mode(VORS_LM_MARGS, 1, split, s);
     const int base_chunks = std::max(1, split.chunks / 4);
     for (int r = 0; r < split.rounds; ++r) {
         // every pair needs at least two evaluations per level: full grids. Later rounds concern fewer and fewer pairs, finally a
         // handful of stragglers whose evaluations are pure latency: they are cut into 4x more chunks and get small grids
         // (grid-stride loops keep any count correct).
-        const int late = r >= 2 * split.n_split + 2;
+        const int late_from = 2 * split.n_split + 2;
+        const int late = r >= late_from, next_late = r + 1 >= late_from;
         split.chunks0 = late ? split.chunks : base_chunks;
         const int full = n_pairs * split.chunks0;
         const int shrink = r < 2 * split.n_split ? 1 : (late ? 16 : 2);
         const int grid = std::max(std::min(full, 256), full / shrink);
-        if (g.huber_delta > 0.f)
-            hipLaunchKernelGGL(lm_split_eval_kernel<true>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, r, late);
-        else
-            hipLaunchKernelGGL(lm_split_eval_kernel<false>, dim3(grid), dim3(SPLIT_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper,
-                               kf_depth, rec, split, r, late);
-        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r, late);
+        // Until the late rounds the pairs march roughly in step: full evaluations (a level's init, or the g / H of a candidate
+        // that goes on) dominate the even rounds, candidates' energies the odd ones; the other kind gets a small grid.
+        const int minor = std::max(std::min(full, 256), grid / 8);
+        const int grid_full = late ? grid : ((r & 1) ? minor : grid), grid_energy = (r & 1) ? grid : minor;
+#define VORS_SPLIT_KARGS g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, split, r
+        if (g.huber_delta > 0.f) {
+            hipLaunchKernelGGL((lm_split_eval_kernel<true, false>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<true, true>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+        } else {
+            hipLaunchKernelGGL((lm_split_eval_kernel<false, false>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<false, true>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+        }
+#undef VORS_SPLIT_KARGS
+        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r, late, next_late);
     }
     // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
     launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
