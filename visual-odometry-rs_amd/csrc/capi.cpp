@@ -363,8 +363,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     STAGE_END(b, 0, s);
     STAGE_BEGIN(b, 1, s);
     if (b->g.mode == VORS_CANDIDATES_DSO) {
-        launch_dso_mask(b->g, kf, b->dso, b->mask0, n_pairs, s);
-        launch_keyframe_generic(b->g, kf, d_kf_depth, b->mask0, b->pp, b->rec, n_pairs, s);
+        launch_keyframe_dso(b->g, kf, d_kf_depth, b->dso, b->mask0, b->pp, b->rec, n_pairs, s);
     } else {
         launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
     }
@@ -382,8 +381,7 @@ static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint1
     Pyramid kf{b->kf_level0, b->kf_upper};
     STAGE_BEGIN(b, 1, s);
     if (b->g.mode == VORS_CANDIDATES_DSO) {
-        launch_dso_mask(b->g, kf, b->dso, b->mask0, n_pairs, s);
-        launch_keyframe_generic(b->g, kf, d_depth, b->mask0, b->pp, b->rec, n_pairs, s);
+        launch_keyframe_dso(b->g, kf, d_depth, b->dso, b->mask0, b->pp, b->rec, n_pairs, s);
     } else {
         launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
     }

@@ -323,13 +323,12 @@ __global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uin
     }
 }
 
-void launch_dso_mask(const Geom& g, Pyramid kf, DsoWs ws, uint8_t* mask_out, int n_pairs, hipStream_t s) {
+// Selection up to the pick stamps (gradient magnitude + region medians, then all rounds of one pair in one workgroup).
+static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pairs, hipStream_t s) {
     const bool wide_img = g.lv[0].cols % 4 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 4 == 0;
     hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
     hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(1024), 0, s, g, ws);
-    hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 4095) / 4096, n_pairs), dim3(256), 0, s, g, ws, mask_out);
 }
-
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
 // usable pixels compacted in raster order into the record planes (deterministic: per-chunk counts, then prefix sums). The LM
@@ -397,21 +396,47 @@ __global__ __launch_bounds__(256) void mask_idepth_halve_kernel(Geom g, int l, c
 }
 // Level 1 when cols(level 0) % 16 == 0: 8 consecutive level-1 pixels per thread, the 2 x 16 mask bytes below them in two loads;
 // depth is only read under set mask bytes (candidates are sparse).
-__global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
-                                                                       PixelPlanes pp) {
+// FROM_DSO (rows(level 0) even as well): the mask bytes are decided here from the selector's pick stamps (what dso_finalize_kernel
+// does) and written out, and the usable level-0 pixels are counted into their compaction chunks (integer atomics: deterministic)
+// — one pass over the level-0 planes instead of three.
+template <bool FROM_DSO>
+__global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask,
+                                                                       PixelPlanes pp, DsoWs ws) {
     const int pair = blockIdx.y;
     const int rows = g.lv[1].rows, cols = g.lv[1].cols, fc = g.lv[0].cols;
     const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (t0 >= rows * cols) return;
     const int y = t0 / cols, x0 = t0 - y * cols;
     const size_t cb = (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x0;
-    const uint4 m0 = *reinterpret_cast<const uint4*>(mask + cb), m1 = *reinterpret_cast<const uint4*>(mask + cb + fc);
+    uint4 m0, m1;
+    if (FROM_DSO) {
+        const DsoState st = ws.state[pair];
+        const uint4 p0 = *reinterpret_cast<const uint4*>(ws.picked + cb), p1 = *reinterpret_cast<const uint4*>(ws.picked + cb + fc);
+        uint32_t in[2][4] = {{p0.x, p0.y, p0.z, p0.w}, {p1.x, p1.y, p1.z, p1.w}}, out[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if ((p0.x | p0.y | p0.z | p0.w | p1.x | p1.y | p1.z | p1.w) != 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int stamp = (in[r][k >> 2] >> (8 * (k & 3))) & 0xff;
+                    if (stamp) out[r][k >> 2] |= (uint32_t)dso_final_mask(st, stamp, (2 * y + r) * fc + 2 * x0 + k, fc) << (8 * (k & 3));
+                }
+        }
+        m0 = make_uint4(out[0][0], out[0][1], out[0][2], out[0][3]);
+        m1 = make_uint4(out[1][0], out[1][1], out[1][2], out[1][3]);
+        *reinterpret_cast<uint4*>(mask + cb) = m0;
+        *reinterpret_cast<uint4*>(mask + cb + fc) = m1;
+    } else {
+        m0 = *reinterpret_cast<const uint4*>(mask + cb);
+        m1 = *reinterpret_cast<const uint4*>(mask + cb + fc);
+    }
     float od[8], ov[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         od[k] = __builtin_nanf("");
         ov[k] = -1.0f;
     }
+    int n_row[2] = {0, 0};  // usable level-0 pixels in the two rows this thread covers
     if ((m0.x | m0.y | m0.z | m0.w | m1.x | m1.y | m1.z | m1.w) != 0) {
         const uint32_t w0[4] = {m0.x, m0.y, m0.z, m0.w}, w1[4] = {m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
@@ -427,7 +452,10 @@ __global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, co
             for (int m = 0; m < 4; ++m) {
                 if (!mk[m]) continue;
                 const uint16_t dz = depth[idx[m]];
-                if (dz != 0) dv[n++] = g.depth_scale / (float)dz;
+                if (dz != 0) {
+                    dv[n++] = g.depth_scale / (float)dz;
+                    n_row[m & 1] += 1;
+                }
             }
             const float v = g.idepth_variance;
             if (n == 1) {
@@ -444,6 +472,14 @@ __global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, co
                 od[k] = (dv[0] * v + dv[1] * v + dv[2] * v + dv[3] * v) / ov[k];
             }
         }
+    }
+    if (FROM_DSO) {  // candidates are sparse: few threads get here with a non-zero count
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (n_row[r]) {
+                const int px = (2 * y + r) * fc + 2 * x0;  // the 16 pixels of a row segment never straddle a 4096-pixel chunk (px % 16 == 0)
+                atomicAdd(&pp.counts[(size_t)pair * pp.chunks_total + pp.chunk_off[0] + px / VORS_CHUNK_PX], n_row[r]);
+            }
     }
     const size_t o = (size_t)pair * pp.stride + pp.off[1] + t0;
     reinterpret_cast<float4*>(pp.iz + o)[0] = make_float4(od[0], od[1], od[2], od[3]);
@@ -509,9 +545,9 @@ __device__ __forceinline__ unsigned usable16(const Geom& g, const PixelPlanes& p
     return vb;
 }
 __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
-                                                             PixelPlanes pp) {
+                                                             PixelPlanes pp, int first_chunk) {
     __shared__ int s_wave[4];
-    const int pair = blockIdx.y, c = blockIdx.x;
+    const int pair = blockIdx.y, c = first_chunk + blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int n = g.lv[l].rows * g.lv[l].cols;
     const int t0 = (c - pp.chunk_off[l]) * VORS_CHUNK_PX + threadIdx.x * 16;
@@ -569,17 +605,33 @@ __global__ __launch_bounds__(256) void generic_records_kernel(Geom g, const uint
     if (c + 1 == pp.chunk_off[l + 1] && threadIdx.x == 255) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l] = min(slot, cap);
 }
 
-void launch_keyframe_generic(const Geom& g, Pyramid kf, const uint16_t* depth, const uint8_t* mask, PixelPlanes pp, Records rec,
-                             int n_pairs, hipStream_t s) {
+// `dso` non-null: the mask is still in the selector's pick stamps; the fused level-1 pass finalizes it into `mask` on the way.
+static void keyframe_from_mask(const Geom& g, Pyramid kf, const uint16_t* depth, uint8_t* mask, PixelPlanes pp, Records rec, const DsoWs* dso,
+                               int n_pairs, hipStream_t s) {
+    int first_chunk = 0;
     for (int l = 1; l < g.L; ++l) {
         const int n = g.lv[l].rows * g.lv[l].cols;
-        if (l == 1 && g.lv[0].cols % 16 == 0)
-            hipLaunchKernelGGL(mask_idepth_level1_wide_kernel, dim3((n / 8 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, mask, pp);
-        else
+        if (l == 1 && dso) {  // (the caller checked the shape: cols % 16 == 0, rows even)
+            (void)hipMemsetAsync(pp.counts, 0, (size_t)n_pairs * pp.chunks_total * sizeof(int), s);
+            hipLaunchKernelGGL(mask_idepth_level1_wide_kernel<true>, dim3((n / 8 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, mask, pp, *dso);
+            first_chunk = pp.chunk_off[1];  // the level-0 chunks have been counted
+        } else if (l == 1 && g.lv[0].cols % 16 == 0) {
+            hipLaunchKernelGGL(mask_idepth_level1_wide_kernel<false>, dim3((n / 8 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, mask, pp, DsoWs{});
+        } else {
             hipLaunchKernelGGL(mask_idepth_halve_kernel, dim3((n + 255) / 256, n_pairs), dim3(256), 0, s, g, l, depth, mask, pp);
+        }
     }
-    hipLaunchKernelGGL(generic_count_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, depth, mask, pp);
+    hipLaunchKernelGGL(generic_count_kernel, dim3(pp.chunks_total - first_chunk, n_pairs), dim3(256), 0, s, g, depth, mask, pp, first_chunk);
     hipLaunchKernelGGL(generic_records_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, kf.level0, kf.upper, depth, mask, pp, rec);
+}
+// DSO-style selection + keyframe precompute. When the shape allows it (level 1 exists, cols % 16 == 0, rows even) the mask is
+// finalized inside the level-1 inverse-depth pass (one pass over the level-0 planes instead of three).
+void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
+                         hipStream_t s) {
+    const bool fused = g.L >= 2 && g.lv[0].cols % 16 == 0 && g.lv[0].rows % 2 == 0;
+    launch_dso_selection(g, kf, ws, n_pairs, s);
+    if (!fused) hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 4095) / 4096, n_pairs), dim3(256), 0, s, g, ws, mask);
+    keyframe_from_mask(g, kf, depth, mask, pp, rec, fused ? &ws : nullptr, n_pairs, s);
 }
 
 }  // namespace vors

@@ -120,9 +120,8 @@ void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int
 void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
-void launch_dso_mask(const Geom& g, Pyramid kf, DsoWs ws, uint8_t* mask_out, int n_pairs, hipStream_t s);
-void launch_keyframe_generic(const Geom& g, Pyramid kf, const uint16_t* depth, const uint8_t* mask, PixelPlanes pp, Records rec,
-                             int n_pairs, hipStream_t s);
+void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
+                         hipStream_t s);
 void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
                               hipStream_t s);
 // `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).
