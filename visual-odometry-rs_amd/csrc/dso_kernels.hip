@@ -558,15 +558,15 @@ __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16
     __syncthreads();
     if (threadIdx.x == 0) pp.counts[(size_t)pair * pp.chunks_total + c] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
-__global__ __launch_bounds__(256) void generic_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
-                                                               const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
+// Compaction: the usable pixels of a level, in raster order, get consecutive slots; only their coordinates are written here (the
+// candidates are sparse: a handful of lanes per wavefront do this part), the records follow in a dense pass over the slots.
+__global__ __launch_bounds__(256) void generic_compact_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                                PixelPlanes pp, Records rec) {
     __shared__ int s_before[4], s_wave[4];
     const int pair = blockIdx.y, c = blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int rows = g.lv[l].rows, cols = g.lv[l].cols, n = rows * cols, cap = g.lv[l].n_slots;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
     const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
     const int* counts = pp.counts + (size_t)pair * pp.chunks_total;
     // first slot of this chunk = usable pixels in the earlier chunks of the level
@@ -595,14 +595,29 @@ __global__ __launch_bounds__(256) void generic_records_kernel(Geom g, const uint
         if (slot < cap) {
             const int t = t0 + k;
             const int y = t / cols, x = t - y * cols;
-            int gx, gy;
-            grad_at(g, kf0, kfu, pair, l, x, y, &gx, &gy);
-            generic_write_record(rec, slot0 + slot, g.lv[l].k, x, y, generic_idepth(g, pp, depth, mask, pair, l, t), gx, gy, img[t]);
+            rec.XY[slot0 + slot] = (uint32_t)x | ((uint32_t)y << 16);
         }
         ++slot;
     }
     // the last thread of the level's last chunk publishes how many of the level's slots are in use
     if (c + 1 == pp.chunk_off[l + 1] && threadIdx.x == 255) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l] = min(slot, cap);
+}
+// One thread per slot in use (grid-stride over a level's slots with GENERIC_BUILD_WGS workgroups): the record of the pixel.
+#define GENERIC_BUILD_WGS 4
+__global__ __launch_bounds__(256) void generic_build_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                     const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                                     PixelPlanes pp, Records rec) {
+    const int pair = blockIdx.y, l = blockIdx.x / GENERIC_BUILD_WGS, w = blockIdx.x - l * GENERIC_BUILD_WGS;
+    const int n = rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l], cols = g.lv[l].cols;
+    const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
+    const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
+    for (int slot = w * 256 + threadIdx.x; slot < n; slot += GENERIC_BUILD_WGS * 256) {
+        const uint32_t xy = rec.XY[slot0 + slot];
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), t = y * cols + x;
+        int gx, gy;
+        grad_at(g, kf0, kfu, pair, l, x, y, &gx, &gy);
+        generic_write_record(rec, slot0 + slot, g.lv[l].k, x, y, generic_idepth(g, pp, depth, mask, pair, l, t), gx, gy, img[t]);
+    }
 }
 
 // `dso` non-null: the mask is still in the selector's pick stamps; the fused level-1 pass finalizes it into `mask` on the way.
@@ -622,7 +637,9 @@ static void keyframe_from_mask(const Geom& g, Pyramid kf, const uint16_t* depth,
         }
     }
     hipLaunchKernelGGL(generic_count_kernel, dim3(pp.chunks_total - first_chunk, n_pairs), dim3(256), 0, s, g, depth, mask, pp, first_chunk);
-    hipLaunchKernelGGL(generic_records_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, kf.level0, kf.upper, depth, mask, pp, rec);
+    hipLaunchKernelGGL(generic_compact_kernel, dim3(pp.chunks_total, n_pairs), dim3(256), 0, s, g, depth, mask, pp, rec);
+    hipLaunchKernelGGL(generic_build_records_kernel, dim3(GENERIC_BUILD_WGS * g.L, n_pairs), dim3(256), 0, s, g, kf.level0, kf.upper, depth, mask, pp,
+                       rec);
 }
 // DSO-style selection + keyframe precompute. When the shape allows it (level 1 exists, cols % 16 == 0, rows even) the mask is
 // finalized inside the level-1 inverse-depth pass (one pass over the level-0 planes instead of three).
