@@ -502,3 +502,18 @@ def test_optional_outputs_and_host_buffer_entry(mode):
     hp2, hs2, hst2 = V.track_pairs(vcfg(L, intr, mode), np.ascontiguousarray(kg.transpose(0, 2, 1)), np.ascontiguousarray(kd.transpose(0, 2, 1)),
                                    np.ascontiguousarray(cg.transpose(0, 2, 1)), layout=V.COL_MAJOR)  # DMatrix layout
     assert (hp2 == poses).all() and (hst2["n_points"][:, :L] == stats["n_points"][:, :L]).all()
+
+
+def test_fast_division_is_bit_identical_to_ieee_division(monkeypatch):
+    """Dense mode divides by the focal lengths with a 3-instruction sequence that is only enabled after an exhaustive on-device
+    check against IEEE division (lie.h div_uniform, kernels.hip verify_fastdiv_kernel). VORS_NO_FASTDIV=1 forces plain division:
+    every pose must come out bit-identical, at a size that uses the wide-load sources and one that uses the fallback source."""
+    for rows, cols, L in ((240, 320, 5), (97, 131, 3)):
+        intr = (cols * 0.5 - 0.5, rows * 0.5 - 0.5, 0.83 * cols, -0.79 * cols, 0.11)   # a negative focal length and skew as well
+        kg, kd, cg, cd, gt = O.synth_batch(6, rows, cols, seed0=0x5EED9900, intr=intr)
+        monkeypatch.delenv("VORS_NO_FASTDIV", raising=False)
+        _, p_fast, s_fast, st_fast, _ = run_batch(vcfg(L, intr, 1), kg, kd, cg)
+        monkeypatch.setenv("VORS_NO_FASTDIV", "1")
+        _, p_ieee, s_ieee, st_ieee, _ = run_batch(vcfg(L, intr, 1), kg, kd, cg)
+        assert (bits(p_fast) == bits(p_ieee)).all() and (s_fast == s_ieee).all()
+        assert (st_fast["nb_iter"] == st_ieee["nb_iter"]).all() and (bits(st_fast["energy"]) == bits(st_ieee["energy"])).all()
