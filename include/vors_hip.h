@@ -130,7 +130,15 @@ vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_
                                    vors_pair_stats* d_out_stats /* nullable */, void* hip_stream);
 /* The three stages of the above, separately (keyframe data persists in the handle between calls):
  *   prepare_keyframes = mean_pyramid + precompute_multires_data        inverse_compositional.rs:83-85,105-161
- *   track_current     = mean_pyramid + coarse->fine LM + keyframe test  inverse_compositional.rs:177-224 */
+ *   track_current     = mean_pyramid + coarse->fine LM + keyframe test  inverse_compositional.rs:177-224
+ * LIFETIME CONTRACT (zero copy, like the reference, which MOVES the image into the pyramid as level 0, multires.rs:14-15):
+ * the handle keeps the caller's POINTERS to level 0 and to the depth map, not copies.
+ *   - VORS_CANDIDATES_DENSE: d_kf_gray and d_kf_depth are re-read by every track_current (points are recomputed from them on the
+ *     fly); they must stay allocated and unchanged until the next prepare_keyframes on this handle or its destruction.
+ *   - coarse-to-fine / DSO: they are read during prepare_keyframes only (everything later needs is in the handle's records);
+ *     vors_batch_get_keyframe_image(level 0) still reads d_kf_gray.
+ * track_current accepts n_pairs <= the n_pairs of the last prepare_keyframes (more would read keyframe slots never prepared) and
+ * fails with VORS_ERR_INVALID_ARGUMENT otherwise. */
 vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
                                          void* hip_stream);
 vors_status vors_batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,

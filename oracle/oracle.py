@@ -77,6 +77,40 @@ def _f64(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+_variants = {}
+
+
+def _cpu_id():
+    try:
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        model = [l for l in txt.splitlines() if l.startswith("model name")][:1]
+        flags = [l for l in txt.splitlines() if l.startswith("flags")][:1]
+        import hashlib
+        return (model[0] if model else "?") + " " + hashlib.sha1((flags[0] if flags else "").encode()).hexdigest()[:12]
+    except OSError:
+        return "unknown"
+
+
+def variant_lib(name):
+    """A sensitivity / baseline build of the same sources (oracle/Makefile): "acc64" (f64 sums), "nalg<bit>" (one nalgebra
+    assumption swapped), "native" (-march=native, for the CPU baseline; built on the host that runs it). NOT the oracle:
+    only vo_track_pairs is bound."""
+    if name not in _variants:
+        path = os.path.join(_HERE, f"libvors_oracle_{name}.so")
+        if name == "native":
+            tag = os.path.join(_HERE, "libvors_oracle_native.cpu")
+            have = open(tag).read() if os.path.exists(tag) and os.path.exists(path) else None
+            if have != _cpu_id():
+                subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+                with open(tag, "w") as f:
+                    f.write(_cpu_id())
+        elif not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _variants[name] = C.CDLL(path)
+    return _variants[name]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -306,8 +340,9 @@ def lm_step(H, g, model7, lm_coef):
     return st, out, delta
 
 
-def track_pairs(cfg, kf_gray, kf_depth, cur_gray, cur_depth=None, init_poses7=None, n_threads=1):
-    """Per pair: Config::init(keyframe) + Tracker::track(current). Returns dict of arrays."""
+def track_pairs(cfg, kf_gray, kf_depth, cur_gray, cur_depth=None, init_poses7=None, n_threads=1, variant=None):
+    """Per pair: Config::init(keyframe) + Tracker::track(current). Returns dict of arrays.
+    variant: None = the oracle; otherwise a sensitivity / baseline build (see variant_lib)."""
     n, rows, cols = kf_gray.shape
     L = cfg.nb_levels
     poses = np.zeros((n, 7), np.float32)
@@ -323,7 +358,7 @@ def track_pairs(cfg, kf_gray, kf_depth, cur_gray, cur_depth=None, init_poses7=No
         cur_depth = np.ascontiguousarray(cur_depth, np.uint16)
     if init_poses7 is not None:
         init_poses7 = np.ascontiguousarray(init_poses7, np.float32)
-    lib().vo_track_pairs(C.byref(cfg), n, _u8(kf_gray), _u16(kf_depth), _u8(cur_gray), _opt(cur_depth, _u16), rows, cols,
+    (variant_lib(variant) if variant else lib()).vo_track_pairs(C.byref(cfg), n, _u8(kf_gray), _u16(kf_depth), _u8(cur_gray), _opt(cur_depth, _u16), rows, cols,
                          _opt(init_poses7, _f32), _f32(poses), _i32(status), _f32(models), _i32(nb_iter), _i32(n_points),
                          _f32(flow), n_threads)
     return dict(poses=poses, models=models, status=status, nb_iter=nb_iter, n_points=n_points, flow=flow)

@@ -18,11 +18,25 @@
 // Third-party arithmetic that is NOT in /root/reference: nalgebra 0.17 (Cargo.toml:20, exact patch
 // unpinned, Cargo.lock git-ignored). Its semantics are restated from its published source from memory
 // and each such block is marked "nalgebra assumption".
+//
+// SENSITIVITY VARIANTS (never "the oracle"; probes built as separate libraries by oracle/Makefile):
+//   -DVORS_ORACLE_ACC64          energy / gradient / Hessian / optical-flow sums accumulate in f64 (per-point arithmetic stays f32):
+//                                how much of a pose is decided by the f32 summation order the GPU cannot reproduce.
+//   -DVORS_ORACLE_NALG_VARIANT=m each bit swaps ONE "nalgebra assumption" for the other plausible evaluation order (<= 1 ulp each):
+//                                1 quaternion product scalar part as w1 w2 - i1 i2 - j1 j2 - k1 k2 (left to right);
+//                                2 3-/4-vector dots folded the other way; 4 q * v as (p + w t) + qv x t; 8 right-looking
+//                                (outer-product) Cholesky and solve by multiplication with reciprocal pivots;
+//                                16 from_quaternion multiplies by 1/norm.
+//                                tests/test_oracle_sensitivity.py reports the pose each choice moves.
 #pragma once
+#ifndef VORS_ORACLE_NALG_VARIANT
+#define VORS_ORACLE_NALG_VARIANT 0
+#endif
 #include <cmath>
 #include <cstddef>
 #include <algorithm>
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -31,6 +45,11 @@ namespace vors_oracle {
 
 // src/misc/type_aliases.rs:10
 typedef float Float;
+#ifdef VORS_ORACLE_ACC64
+typedef double Acc;  // sensitivity probe only
+#else
+typedef float Acc;   // the reference: f32 sums (lm_optimizer.rs:72-100)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Containers and small algebra (nalgebra restatement)
@@ -84,10 +103,14 @@ inline Vec3 cross(const Vec3& a, const Vec3& b) {
     return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 // nalgebra assumption: static U3 dot special case = (a + b) + c.
-inline Float dot3(const Vec3& a, const Vec3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline Float dot3(const Vec3& a, const Vec3& b) {
+    if (VORS_ORACLE_NALG_VARIANT & 2) return a.x * b.x + (a.y * b.y + a.z * b.z);
+    return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
 // nalgebra assumption: static U4 dot special case: a=x0*y0, b=x1*y1, c=x2*y2, d=x3*y3; (a+c)+(b+d).
 inline Float quat_norm_squared(const Quat& q) {
     Float a = q.i * q.i, b = q.j * q.j, c = q.k * q.k, d = q.w * q.w;
+    if (VORS_ORACLE_NALG_VARIANT & 2) return ((a + b) + c) + d;
     a += c;
     b += d;
     return a + b;
@@ -98,12 +121,14 @@ inline Vec3 quat_rotate(const Quat& q, const Vec3& p) {
     Vec3 t = cross(qv, p);
     t = Vec3{t.x * 2.0f, t.y * 2.0f, t.z * 2.0f};
     const Vec3 c = cross(qv, t);
+    if (VORS_ORACLE_NALG_VARIANT & 4) return Vec3{(p.x + q.w * t.x) + c.x, (p.y + q.w * t.y) + c.y, (p.z + q.w * t.z) + c.z};
     return Vec3{(t.x * q.w + c.x) + p.x, (t.y * q.w + c.y) + p.y, (t.z * q.w + c.z) + p.z};
 }
 // nalgebra assumption: Quaternion * Quaternion (Hamilton), scalar part uses vector dot.
 inline Quat quat_mul(const Quat& a, const Quat& b) {
     Quat r;
     r.w = a.w * b.w - dot3(Vec3{a.i, a.j, a.k}, Vec3{b.i, b.j, b.k});
+    if (VORS_ORACLE_NALG_VARIANT & 1) r.w = a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k;
     r.i = a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j;
     r.j = a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i;
     r.k = a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w;
@@ -113,6 +138,10 @@ inline Quat quat_conj(const Quat& q) { return Quat{-q.i, -q.j, -q.k, q.w}; }
 // nalgebra assumption: UnitQuaternion::from_quaternion = q / sqrt(norm_squared), per-coordinate division.
 inline Quat unit_from_quaternion(const Quat& q) {
     const Float n = std::sqrt(quat_norm_squared(q));
+    if (VORS_ORACLE_NALG_VARIANT & 16) {
+        const Float r = 1.0f / n;
+        return Quat{q.i * r, q.j * r, q.k * r, q.w * r};
+    }
     return Quat{q.i / n, q.j / n, q.k / n, q.w / n};
 }
 // nalgebra assumption: Isometry * Point = rotation*p + translation.
@@ -136,6 +165,18 @@ inline Iso3 iso_inverse(const Iso3& a) {
 // Cholesky::solve (forward substitution by columns with axpy, backward substitution with a sequential dot).
 // Returns false where nalgebra returns None (lm_optimizer.rs:131-133).
 inline bool cholesky6(Mat6& a) {
+    if (VORS_ORACLE_NALG_VARIANT & 8) {  // right-looking: scale the column, then the rank-1 update of the trailing block
+        for (int j = 0; j < 6; ++j) {
+            const Float diag = a.m[j][j];
+            if (!(diag > 0.0f)) return false;
+            const Float denom = std::sqrt(diag), inv = 1.0f / denom;
+            a.m[j][j] = denom;
+            for (int i = j + 1; i < 6; ++i) a.m[i][j] *= inv;
+            for (int c = j + 1; c < 6; ++c)
+                for (int i = c; i < 6; ++i) a.m[i][c] -= a.m[i][j] * a.m[c][j];
+        }
+        return true;
+    }
     for (int j = 0; j < 6; ++j) {
         for (int k = 0; k < j; ++k) {
             const Float factor = -a.m[j][k];
@@ -154,6 +195,19 @@ inline bool cholesky6(Mat6& a) {
 }
 inline Vec6 cholesky6_solve(const Mat6& l, const Vec6& rhs) {
     Vec6 b = rhs;
+    if (VORS_ORACLE_NALG_VARIANT & 8) {
+        for (int i = 0; i < 6; ++i) {
+            Float acc = b.v[i];
+            for (int k = 0; k < i; ++k) acc -= l.m[i][k] * b.v[k];
+            b.v[i] = acc * (1.0f / l.m[i][i]);
+        }
+        for (int i = 5; i >= 0; --i) {
+            Float acc = b.v[i];
+            for (int k = 5; k > i; --k) acc -= l.m[k][i] * b.v[k];
+            b.v[i] = acc * (1.0f / l.m[i][i]);
+        }
+        return b;
+    }
     for (int i = 0; i < 6; ++i) {
         const Float coeff = b.v[i] / l.m[i][i];
         b.v[i] = coeff;
@@ -563,7 +617,10 @@ inline DMatrix<uint16_t> region_median_gradients(const DMatrix<uint16_t>& g, siz
         }
     return out;
 }
-// dso.rs:284-303: threshold = a * (mean3x3(median) + b)^2, cast to u16 (truncation)
+// dso.rs:284-303: threshold = a * (mean3x3(median) + b)^2, cast to u16 (truncation). The reference's num_traits::cast(..)
+// .expect("woops") panics when the value does not fit u16; with the input of examples/candidates_dso.rs:42 (gradient magnitudes
+// sqrt(g2 / 4) <= 180, a = 1, b = 3) the value is at most (180 + 3)^2 = 33,489, so the panic is unreachable on this path and the
+// plain cast below never wraps (asserted).
 inline DMatrix<uint16_t> region_thresholds(const DMatrix<uint16_t>& med, Float a, uint16_t b) {
     const int nr = med.nrows, nc = med.ncols;
     DMatrix<uint16_t> out(nr, nc, 0);
@@ -578,6 +635,7 @@ inline DMatrix<uint16_t> region_thresholds(const DMatrix<uint16_t>& med, Float a
                     ++n;
                 }
             const Float t = (Float)sum / (Float)n + (Float)b;
+            if (!(a * t * t < 65536.0f)) throw std::runtime_error("woops");  // the reference panics here (dso.rs:300)
             out(i, j) = (uint16_t)(a * t * t);
         }
     return out;
@@ -818,7 +876,7 @@ struct LMOptimizerState {  // lm_optimizer.rs:16-21
     // lm_optimizer.rs:68-87
     static Precomputed eval_energy(const Obs& obs, const Iso3& model) {
         Precomputed pre;
-        Float energy_sum = 0.0f;
+        Acc energy_sum = 0;
         const auto& coords = *obs.coordinates;
         for (size_t idx = 0; idx < coords.size(); ++idx) {
             const size_t x = coords[idx].first, y = coords[idx].second;
@@ -830,23 +888,24 @@ struct LMOptimizerState {  // lm_optimizer.rs:16-21
                 const Float r = im - (Float)tmp;
                 if (obs.huber_delta > 0.0f) {  // extension, parity unpinned
                     const Float ar = std::fabs(r);
-                    energy_sum += (ar <= obs.huber_delta) ? r * r : obs.huber_delta * (2.0f * ar - obs.huber_delta);
+                    energy_sum += (Acc)((ar <= obs.huber_delta) ? r * r : obs.huber_delta * (2.0f * ar - obs.huber_delta));
                 } else {
-                    energy_sum += r * r;
+                    energy_sum += (Acc)(r * r);
                 }
                 pre.residuals.push_back(r);
                 pre.inside_indices.push_back(idx);
             }
         }
-        pre.energy = energy_sum / (Float)pre.residuals.size();
+        pre.energy = (Float)(energy_sum / (Acc)pre.residuals.size());
         return pre;
     }
     // lm_optimizer.rs:90-107
     static EvalData compute_eval_data(const Obs& obs, const Iso3& model, const Precomputed& pre) {
         EvalData e;
+        Acc grad[6], hess[6][6];
         for (int a = 0; a < 6; ++a) {
-            e.gradient.v[a] = 0.0f;
-            for (int b = 0; b < 6; ++b) e.hessian.m[a][b] = 0.0f;
+            grad[a] = 0;
+            for (int b = 0; b < 6; ++b) hess[a][b] = 0;
         }
         for (size_t i = 0; i < pre.inside_indices.size(); ++i) {
             const size_t idx = pre.inside_indices[i];
@@ -856,14 +915,18 @@ struct LMOptimizerState {  // lm_optimizer.rs:16-21
             if (obs.huber_delta > 0.0f) {  // extension
                 const Float ar = std::fabs(r);
                 const Float w = (ar <= obs.huber_delta) ? 1.0f : obs.huber_delta / ar;
-                for (int a = 0; a < 6; ++a) e.gradient.v[a] += jac.v[a] * (w * r);
+                for (int a = 0; a < 6; ++a) grad[a] += (Acc)(jac.v[a] * (w * r));
                 for (int a = 0; a < 6; ++a)
-                    for (int b = 0; b < 6; ++b) e.hessian.m[a][b] += w * hes.m[a][b];
+                    for (int b = 0; b < 6; ++b) hess[a][b] += (Acc)(w * hes.m[a][b]);
             } else {
-                for (int a = 0; a < 6; ++a) e.gradient.v[a] += jac.v[a] * r;
+                for (int a = 0; a < 6; ++a) grad[a] += (Acc)(jac.v[a] * r);
                 for (int a = 0; a < 6; ++a)
-                    for (int b = 0; b < 6; ++b) e.hessian.m[a][b] += hes.m[a][b];
+                    for (int b = 0; b < 6; ++b) hess[a][b] += (Acc)hes.m[a][b];
             }
+        }
+        for (int a = 0; a < 6; ++a) {
+            e.gradient.v[a] = (Float)grad[a];
+            for (int b = 0; b < 6; ++b) e.hessian.m[a][b] = (Float)hess[a][b];
         }
         e.energy = pre.energy;
         e.model = model;
@@ -1155,14 +1218,14 @@ struct Tracker {  // inverse_compositional.rs:31-34 + 52-60
         // keyframe test on the coarsest level (inverse_compositional.rs:211-224)
         const auto& last = keyframe_data.usable_candidates_multires.back();
         const Intrinsics& intr = keyframe_data.intrinsics_multires.back();
-        Float optical_flow_sum = 0.0f;
+        Acc optical_flow_sum = 0;
         for (size_t k = 0; k < last.second.size(); ++k) {
             const Float x = (Float)last.first[k].first, y = (Float)last.first[k].second;
             Float u, v;
             lm_optimizer::warp(lm_model, x, y, last.second[k], intr, u, v);
-            optical_flow_sum += std::fabs(x - u) + std::fabs(y - v);
+            optical_flow_sum += (Acc)(std::fabs(x - u) + std::fabs(y - v));
         }
-        const Float optical_flow = optical_flow_sum / (Float)last.second.size();
+        const Float optical_flow = (Float)(optical_flow_sum / (Acc)last.second.size());
         const bool change_keyframe = optical_flow >= 1.0f;
         last_optical_flow = optical_flow;
         last_changed_keyframe = change_keyframe;

@@ -1,13 +1,20 @@
-"""World-size-2 gloo test of the N>1 path's host logic (sharding by contiguous blocks + the single pose all-gather)."""
+"""World-size-2 tests of the N>1 path: sharding by contiguous blocks + the single all-gather of (pose 7 + status) per pair.
+
+CPU (gloo): the host logic with stand-in results, including uneven and empty shards.
+GPU (gloo control plane, both ranks on cuda:0): the REAL engine — each rank runs its own vors_batch on its shard_range of the
+batch and the gathered result must be bit-identical to a single-process batch over all pairs. This is bench.py's N>1 code path
+minus RCCL (the driver's 8-GPU node runs it with backend "nccl").
+"""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vors_amd.distributed import gather_poses, shard_range
+from vors_amd.distributed import gather_poses, gather_results, shard_range, shard_size
 
 
 def _free_port():
@@ -18,38 +25,59 @@ def _free_port():
     return p
 
 
+def _spawn(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
 def _worker(rank, world, port, n_total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(n_total, rank, world)
-    # stand-in for the per-rank HIP batch: pose of global pair i encodes i (the kernels are covered by the gpu tests)
-    local = torch.stack([torch.full((7,), float(i)) for i in range(lo, hi)])
-    out = gather_poses(local)
+    # stand-in for the per-rank HIP batch: pose of global pair i encodes i, status = i % 2 (the kernels are covered by the gpu tests)
+    local = torch.stack([torch.full((7,), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros((0, 7))
+    status = torch.tensor([i % 2 for i in range(lo, hi)], dtype=torch.int32)
+    poses, st = gather_results(local, status, n_total)
+    equal = gather_poses(torch.full((3, 8), float(rank)))   # bench.py's equal-P fast path
     # timing protocol of bench.py: barrier, then MAX over ranks of the elapsed time
     dist.barrier()
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    q.put((rank, lo, hi, out.numpy().copy(), float(t.item())))
+    q.put((rank, lo, hi, poses.numpy().copy(), st.numpy().copy(), equal.numpy().copy(), float(t.item())))
     dist.destroy_process_group()
 
 
-def test_shard_and_gather_world2():
-    world, n_total = 2, 10
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert [(r[1], r[2]) for r in res] == [(0, 5), (5, 10)]
+@pytest.mark.parametrize("world,n_total", [(2, 10), (2, 7), (3, 4), (2, 1)])
+def test_shard_and_gather(world, n_total):
+    res = _spawn(_worker, world, n_total)
+    per = shard_size(n_total, world)
+    assert [(r[1], r[2]) for r in res] == [(min(r * per, n_total), min((r + 1) * per, n_total)) for r in range(world)]
     for r in res:
-        assert (r[3][:, 0] == np.arange(n_total)).all()   # every rank sees all poses, in global pair order
-        assert r[4] == 2.0                                 # MAX over ranks
+        assert r[3].shape == (n_total, 7) and (r[3][:, 0] == np.arange(n_total)).all()   # all poses, in global pair order
+        assert (r[4] == np.arange(n_total) % 2).all()                                     # statuses travel with them
+        assert (r[5][:, 0] == np.repeat(np.arange(world), 3)).all()
+        assert r[6] == float(world)                                                       # MAX over ranks
+
+
+def test_gather_results_rejects_wrong_shard_size():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(ValueError):
+            gather_results(torch.zeros((3, 7)), torch.zeros(3, dtype=torch.int32), n_total=4)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_shard_range_covers_everything_once():
@@ -62,3 +90,54 @@ def test_shard_range_covers_everything_once():
                 seen[lo:hi] += 1
             assert (seen == 1).all()
     assert [shard_range(4096, r, 8) for r in (0, 7)] == [(0, 512), (3584, 4096)]   # BASELINE config 4: 512 per GPU
+
+
+# ---------------------------------------------------------------------------------------------------- real engine, 2 ranks, 1 GPU
+def _gpu_worker(rank, world, port, n_total, mode, rows, cols, L, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vors_amd as V
+    from oracle import oracle as O   # intrinsics helper + nothing else (test process)
+    torch.cuda.set_device(0)
+    intr = O.scaled_intrinsics(rows, cols)
+    lo, hi = shard_range(n_total, rank, world)
+    n = hi - lo
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode)
+    # every rank renders ITS pairs (seed = global pair index), like bench.py
+    kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED2200 + lo, n, rows, cols, intr)
+    b = V.Batch(cfg, n, rows, cols)
+    poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    b.track_pairs(kg, kd, cg, poses, status)
+    torch.cuda.synchronize()
+    all_poses, all_status = gather_results(poses, status, n_total)
+    q.put((rank, all_poses.cpu().numpy(), all_status.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n_total", [(0, 24), (1, 7)], ids=["coarse_to_fine", "dense_uneven"])
+def test_two_ranks_real_engine_equals_single_process(mode, n_total):
+    import vors_amd as V
+    from oracle import oracle as O
+    rows, cols, L = 240, 320, 5
+    res = _spawn(_gpu_worker, 2, n_total, mode, rows, cols, L)
+    intr = O.scaled_intrinsics(rows, cols)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode)
+    kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED2200, n_total, rows, cols, intr)
+    b = V.Batch(cfg, n_total, rows, cols)
+    poses = torch.zeros((n_total, 7), dtype=torch.float32, device="cuda")
+    status = torch.zeros(n_total, dtype=torch.int32, device="cuda")
+    b.track_pairs(kg, kd, cg, poses, status)
+    torch.cuda.synchronize()
+    want_p, want_s = poses.cpu().numpy(), status.cpu().numpy()
+    for rank, got_p, got_s in res:
+        assert (got_p.view(np.uint32) == want_p.view(np.uint32)).all(), f"rank {rank}: sharded poses differ from the single batch"
+        assert (got_s == want_s).all()
+    # and against the oracle (the checker), on a sample
+    k = min(n_total, 6)
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg[:k].cpu().numpy(), kd[:k].cpu().numpy().view(np.uint16),
+                        cg[:k].cpu().numpy())
+    assert np.abs(want_p[:k] - ref["poses"]).max() < 1e-4 and (want_s[:k] == ref["status"]).all()

@@ -150,14 +150,17 @@ def test_lm_solve_and_host_driven_trait_vs_oracle():
         model = m_or
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_tracker_sequence_with_keyframe_switch_vs_oracle(mode):
+@pytest.mark.parametrize("mode,rows,cols,L", [(0, 120, 160, 4), (1, 120, 160, 4), (2, 240, 320, 5), (2, 120, 160, 4)],
+                         ids=["coarse_to_fine", "dense", "dso_320x240", "dso_160x120_recursive"])
+def test_tracker_sequence_with_keyframe_switch_vs_oracle(mode, rows, cols, L):
     """Config::init + repeated Tracker::track along a trajectory long enough to force keyframe changes
-    (mode 1 = dense extension: the keyframe's depth map stays resident and is re-read by the LM kernel)."""
-    rows, cols, L = 120, 160, 4
+    (mode 1 = dense extension: the keyframe's depth map stays resident and is re-read by the LM kernel; mode 2 = BASELINE
+    config 3's shape: a SEQUENCE with DSO candidate selection, examples/candidates_dso.rs:40-59 as the mask source — every keyframe
+    switch re-runs the DSO selector + generic-mask path on the frame that was current, inverse_compositional.rs:224-239)."""
     intr = O.scaled_intrinsics(rows, cols)
     step = np.array([0.012, -0.006, 0.004, 0.002, -0.003, 0.001])
-    frames = [O.synth_frame(77, step * k, rows, cols, intr, frame_salt=k) for k in range(12)]
+    seed = (1 << 63 | 77) if mode == 2 else 77   # DSO thresholds reject the smooth texture: piecewise-constant one
+    frames = [O.synth_frame(seed, step * k, rows, cols, intr, frame_salt=k) for k in range(12)]
     ot = O.Tracker(O.make_config(L, intr, candidates_mode=mode), 0.0, frames[0][1], 0.0, frames[0][0])
     vt = vcfg(L, intr, mode).init(0.0, frames[0][1], 0.0, frames[0][0])
     switches = 0
@@ -174,9 +177,11 @@ def test_tracker_sequence_with_keyframe_switch_vs_oracle(mode):
         switches += int(ol["changed_keyframe"])
         assert np.abs(ot.keyframe_pose()[1] - vt.keyframe()[1]).max() < POSE_TOL
     assert switches >= 1, "the trajectory was meant to trigger at least one keyframe change"
-    # ground truth: camera k pose in frame-0 coordinates = exp(step*k)^-1
+    # ground truth: camera k pose in frame-0 coordinates = exp(step*k)^-1. (A sanity check of the SCENE, not a parity bar: the
+    # drift of 11 chained alignments on quantised images; the oracle shows the same error.)
     gt = O.iso_inverse(O.gt_model7(step * (len(frames) - 1)))
-    assert np.abs(vt.current_frame()[1] - gt).max() < 2e-2
+    assert np.abs(vt.current_frame()[1] - gt).max() < (5e-2 if mode == 2 else 2e-2)
+    assert np.abs(ot.current_frame()[1] - vt.current_frame()[1]).max() < POSE_TOL
 
 
 def test_col_major_layout_equals_row_major():
@@ -264,7 +269,8 @@ def test_icl_nuim_negative_focal_and_skew():
     ref = O.track_pairs(O.make_config(L, intr), kg, kd, cg)
     assert (status == ref["status"]).all()
     ok = status == 0
-    assert np.abs(poses[ok] - ref["poses"][ok]).max(initial=0) < 1e-3
+    assert ok.any()
+    assert np.abs(poses[ok] - ref["poses"][ok]).max(initial=0) < POSE_TOL
 
 
 def test_huber_extension_vs_oracle():
@@ -275,7 +281,7 @@ def test_huber_extension_vs_oracle():
     cg[:, 20:40, 30:60] = 255  # an occluder: outliers for the robust weights
     ref = O.track_pairs(O.make_config(L, intr, huber_delta=10.0), kg, kd, cg)
     poses, status, _ = V.track_pairs(vcfg(L, intr, huber=10.0), kg, kd, cg)
-    assert (status == ref["status"]).all() and np.abs(poses - ref["poses"]).max() < 5e-4
+    assert (status == ref["status"]).all() and np.abs(poses - ref["poses"]).max() < POSE_TOL
 
 
 # ------------------------------------------------------------------------------------------------ full-size properties

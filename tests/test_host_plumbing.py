@@ -36,9 +36,10 @@ def _write_png(path, arr):
 
 def test_host_plumbing_selftest(tmp_path):
     _ensure_host_built()
-    out = subprocess.run([os.path.join(HOST, "host_plumbing_test"), str(tmp_path)], capture_output=True, text=True)
+    fixtures = os.path.join(ROOT, "tests", "golden", "png")   # written by Pillow (independent encoder, filters 0-4)
+    out = subprocess.run([os.path.join(HOST, "host_plumbing_test"), str(tmp_path), fixtures], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "ok" in out.stdout
+    assert "png fixtures: ok" in out.stdout and "host_plumbing_test: ok" in out.stdout
 
 
 def test_cli_argument_errors_match_reference_messages():

@@ -117,6 +117,7 @@ struct vors_batch {
     vors_config cfg;
     Geom g;
     int max_pairs = 0;
+    int prepared_pairs = 0;  // n_pairs of the last prepare_keyframes: track_current may not ask for more
     uint8_t* kf_upper = nullptr;
     uint8_t* cur_upper = nullptr;
     const uint8_t* kf_level0 = nullptr;   // caller's buffer of the last prepare_keyframes
@@ -161,8 +162,10 @@ static void batch_free(vors_batch* b) {
     for (void* p : extra)
         if (p) (void)hipFree(p);
     for (int st = 0; st < 4; ++st) {
-        for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
-        for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
+        for (auto e : b->ev0[st])
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : b->ev1[st])
+            if (e) (void)hipEventDestroy(e);
     }
     delete b;
 }
@@ -217,7 +220,14 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     // Threads per frame pair in the LM kernel. Few pairs: one big workgroup per CU (latency); many pairs: 256-thread
     // workgroups, several per CU, so that pairs with different iteration counts balance (measured).
     b->lm_block = max_pairs >= 512 ? 256 : (g.mode == VORS_CANDIDATES_DENSE ? 1024 : 512);
-    if (const char* e = getenv("VORS_LM_BLOCK")) b->lm_block = atoi(e);  // tuning knob (256 / 512 / 1024)
+    if (const char* e = getenv("VORS_LM_BLOCK")) {  // tuning knob (256 / 512 / 1024)
+        const int v = atoi(e);
+        if (v != 256 && v != 512 && v != 1024) {
+            delete b;
+            return fail(VORS_ERR_INVALID_ARGUMENT, "VORS_LM_BLOCK must be 256, 512 or 1024");
+        }
+        b->lm_block = v;
+    }
     const size_t np = (size_t)max_pairs;
     const size_t slots = np * (size_t)g.slots_total;
     hipError_t e = hipSuccess;
@@ -328,9 +338,12 @@ vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes) {
 vors_status vors_batch_enable_kernel_timing(vors_batch* b, int ring) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
     if (ring < 0 || ring > 4096) return fail(VORS_ERR_INVALID_ARGUMENT, "ring must be in [0, 4096]");
+    b->ring = 0;  // stays off if an event cannot be created below
     for (int st = 0; st < 4; ++st) {
-        for (auto e : b->ev0[st]) (void)hipEventDestroy(e);
-        for (auto e : b->ev1[st]) (void)hipEventDestroy(e);
+        for (auto e : b->ev0[st])
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : b->ev1[st])
+            if (e) (void)hipEventDestroy(e);
         b->ev0[st].assign(ring, nullptr);
         b->ev1[st].assign(ring, nullptr);
         b->count[st] = 0;
@@ -357,6 +370,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     b->kf_level0 = d_kf_gray;
     b->kf_depth = d_kf_depth;
+    b->prepared_pairs = n_pairs;
     Pyramid kf{d_kf_gray, b->kf_upper};
     STAGE_BEGIN(b, 0, s);
     launch_pyramid(b->g, kf, n_pairs, s);
@@ -394,6 +408,9 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
                                        const float* d_kf_poses7, float* d_out_poses7, int32_t* d_out_status,
                                        vors_pair_stats* d_out_stats, hipStream_t s) {
     if (!b->kf_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "track_current called before prepare_keyframes");
+    if (n_pairs > b->prepared_pairs)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "track_current: n_pairs (" + std::to_string(n_pairs) + ") exceeds the " +
+                                                   std::to_string(b->prepared_pairs) + " keyframes prepared on this handle");
     b->cur_level0 = d_cur_gray;
     Pyramid cur{d_cur_gray, b->cur_upper};
     STAGE_BEGIN(b, 2, s);
@@ -425,7 +442,7 @@ vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_
 }
 
 vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int capacity, int* n_out) {
-    if (!b || !n_out || stage < 0 || stage > 3) return fail(VORS_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!b || !n_out || stage < 0 || stage > 3 || (capacity > 0 && !ms_out)) return fail(VORS_ERR_INVALID_ARGUMENT, "bad argument");
     const int n = (int)std::min<long>(b->count[stage], b->ring);
     *n_out = n;
     for (int k = 0; k < n && k < capacity; ++k) {

@@ -543,7 +543,8 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {
         static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
-        const int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
+        int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
+        while (r > 1 && (size_t)KF_WAVES * r * (1 << g.L) * 16 > 64 * 1024) r >>= 1;  // stay inside the 64 KiB a workgroup may ask for
         dim3 grid((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r), n_pairs);
         const size_t lds = (size_t)KF_WAVES * r * (1 << g.L) * 16;
         if (r == 8) hipLaunchKernelGGL(keyframe_sparse_kernel<8>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);

@@ -80,6 +80,48 @@ int main(int argc, char** argv) {
     bool threw = false;
     try { png_io::read_png_16bits(dir + "/vors_t_g.png", w2, h2, d2); } catch (const std::exception&) { threw = true; }
     CHECK(threw);
+    // ---- decoding of files written by an independent encoder (Pillow; adaptive filters 0-4, see tests/golden/make_png_fixtures.py)
+    if (argc > 2) {
+        const std::string fx = argv[2];
+        for (const char* name : {"grey8", "rgb8", "rgba8", "greyalpha8", "palette8", "palette4", "grey1"}) {
+            std::vector<uint8_t> got;
+            png_io::read_luma8(fx + "/" + name + ".png", w2, h2, got);
+            const std::vector<uint8_t> want = png_io::read_file(fx + "/" + name + ".u8");
+            if (got != want) {
+                std::fprintf(stderr, "FAILED: %s.png decodes differently from %s.u8\n", name, name);
+                return 1;
+            }
+        }
+        std::vector<uint16_t> dd;
+        png_io::read_png_16bits(fx + "/depth16.png", w2, h2, dd);
+        const std::vector<uint8_t> want = png_io::read_file(fx + "/depth16.u16le");
+        CHECK(want.size() == dd.size() * 2);
+        for (size_t i = 0; i < dd.size(); ++i) CHECK(dd[i] == (uint16_t)(want[2 * i] | want[2 * i + 1] << 8));
+        threw = false;
+        try { std::vector<uint8_t> l; png_io::read_luma8(fx + "/depth16.png", w2, h2, l); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);  // like image 0.19: no 16-bit DynamicImage
+        // hostile headers: short IHDR, absurd dimensions, truncated stream
+        std::vector<uint8_t> f = png_io::read_file(fx + "/grey8.png");
+        auto expect_throw = [&](std::vector<uint8_t> bad) {
+            try { png_io::decode(bad); } catch (const std::exception&) { return true; }
+            return false;
+        };
+        {
+            std::vector<uint8_t> bad = f;
+            bad[8 + 3] = 12;  // IHDR length 12
+            CHECK(expect_throw(bad));
+            bad = f;
+            bad[16] = 0x7f;  // width = 2^31-ish
+            CHECK(expect_throw(bad));
+            bad = f;
+            bad.resize(bad.size() / 2);
+            CHECK(expect_throw(bad));
+            bad = f;
+            bad[24] = 3;  // bit depth 3
+            CHECK(expect_throw(bad));
+        }
+        std::printf("png fixtures: ok\n");
+    }
     std::printf("host_plumbing_test: ok\n");
     return 0;
 }

@@ -82,11 +82,15 @@ class Tracker {  // inverse_compositional.rs:31-34
    public:
     Tracker(const Tracker&) = delete;
     Tracker& operator=(const Tracker&) = delete;
-    Tracker(Tracker&& o) noexcept : h_(o.h_), log_(o.log_) { o.h_ = nullptr; }
+    Tracker(Tracker&& o) noexcept : h_(o.h_), rows_(o.rows_), cols_(o.cols_), layout_(o.layout_), log_(o.log_) { o.h_ = nullptr; }
     ~Tracker() { vors_tracker_destroy(h_); }
 
     // Tracker::track (inverse_compositional.rs:170-240): returns () like the reference.
     void track(double depth_time, ImageView<std::uint16_t> depth_map, double img_time, ImageView<std::uint8_t> img) {
+        // the C ABI carries no dimensions after create(): a smaller frame would be read past its end
+        if (depth_map.rows != rows_ || depth_map.cols != cols_ || img.rows != rows_ || img.cols != cols_)
+            throw std::invalid_argument("Tracker::track: frame shape differs from the keyframe's");
+        if (depth_map.layout != layout_ || img.layout != layout_) throw std::invalid_argument("Tracker::track: layout differs from init's");
         int status = 0;
         check(vors_tracker_track(h_, depth_time, depth_map.data, img_time, img.data, &status));
         vors_pair_stats s;
@@ -112,8 +116,9 @@ class Tracker {  // inverse_compositional.rs:31-34
 
    private:
     friend struct Config;
-    explicit Tracker(vors_tracker* h) : h_(h) {}
+    Tracker(vors_tracker* h, int rows, int cols, int layout) : h_(h), rows_(rows), cols_(cols), layout_(layout) {}
     vors_tracker* h_ = nullptr;
+    int rows_ = 0, cols_ = 0, layout_ = 0;
     bool log_ = true;
     vors_pair_stats last_{};
     int last_status_ = 0;
@@ -121,11 +126,13 @@ class Tracker {  // inverse_compositional.rs:31-34
 
 inline Tracker Config::init(double keyframe_depth_timestamp, ImageView<std::uint16_t> depth_map, double keyframe_img_timestamp,
                             ImageView<std::uint8_t> img) const {
+    if (depth_map.rows != img.rows || depth_map.cols != img.cols || depth_map.layout != img.layout)
+        throw std::invalid_argument("Config::init: depth map and image differ in shape or layout");
     vors_config c = to_c();
     vors_tracker* h = nullptr;
     check(vors_tracker_create(&c, keyframe_depth_timestamp, depth_map.data, keyframe_img_timestamp, img.data, img.rows, img.cols,
                               img.layout, &h));
-    return Tracker(h);
+    return Tracker(h, img.rows, img.cols, img.layout);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -234,6 +234,10 @@ class Tracker:
         """Tracker::track (inverse_compositional.rs:170-240). Returns the VORS_TRACK_* status (the reference returns ())."""
         img = np.ascontiguousarray(img, np.uint8)
         depth_map = np.ascontiguousarray(depth_map, np.uint16)
+        want = self._shape if self._layout == ROW_MAJOR else self._shape[::-1]
+        if img.shape != want or depth_map.shape != want:  # the C ABI carries no dimensions after create(): check them here
+            raise VorsError(f"Tracker.track: frame shape {img.shape} / depth shape {depth_map.shape} differ from the {want} "
+                            "this tracker was created with")
         st = C.c_int()
         _check(lib().vors_tracker_track(self._h, depth_time, _ptr(depth_map), img_time, _ptr(img), C.byref(st)))
         return st.value
@@ -324,17 +328,32 @@ class Batch:
         _check(lib().vors_batch_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(lm_ms=a.value, keyframe_ms=b.value, pyramid_ms=c.value)
 
+    def _check_images(self, *tensors):
+        for t in tensors:
+            if t is None:
+                continue
+            if tuple(t.shape[-2:]) != (self.rows, self.cols) or not t.is_contiguous() or t.shape[0] > self.max_pairs:
+                raise VorsError(f"expected contiguous [n <= {self.max_pairs}, {self.rows}, {self.cols}] images, got {tuple(t.shape)}")
+
     def prepare_keyframes(self, kf_gray, kf_depth):
         n = kf_gray.shape[0]
+        self._check_images(kf_gray, kf_depth)
+        # lifetime contract of vors_batch_prepare_keyframes: the handle keeps POINTERS to level 0 and the depth map (zero copy);
+        # hold the tensors so that torch's caching allocator cannot hand their memory to someone else while the handle uses them
+        self._kf_refs = (kf_gray, kf_depth)
         _check(lib().vors_batch_prepare_keyframes(self._h, n, self._dp(kf_gray), self._dp(kf_depth), self._stream()))
 
     def track_current(self, cur_gray, out_poses7, out_status, out_stats=None, prev_poses7=None):
         n = cur_gray.shape[0]
+        self._check_images(cur_gray)
+        self._cur_ref = cur_gray
         _check(lib().vors_batch_track_current(self._h, n, self._dp(cur_gray), self._dp(prev_poses7), self._dp(out_poses7),
                                               self._dp(out_status), self._dp(out_stats), self._stream()))
 
     def track_pairs(self, kf_gray, kf_depth, cur_gray, out_poses7, out_status, out_stats=None, prev_poses7=None):
         n = kf_gray.shape[0]
+        self._check_images(kf_gray, kf_depth, cur_gray)
+        self._kf_refs, self._cur_ref = (kf_gray, kf_depth), cur_gray
         _check(lib().vors_batch_track_pairs(self._h, n, self._dp(kf_gray), self._dp(kf_depth), self._dp(cur_gray),
                                             self._dp(prev_poses7), self._dp(out_poses7), self._dp(out_status),
                                             self._dp(out_stats), self._stream()))
