@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--cols", type=int, default=640)
     p.add_argument("--levels", type=int, default=6)
     p.add_argument("--huber", type=float, default=0.0)
+    p.add_argument("--arith", choices=["fused", "exact"], default="fused",
+                   help="per-point arithmetic (include/vors_hip.h VORS_ARITH_*): fused = equivalent shorter f32 forms (poses within the 1e-4 "
+                        "parity bar, gated by tests/test_gpu_fused.py); exact = the reference's evaluation order (parity anchor)")
     p.add_argument("--cpu-pairs", type=int, default=-1, help="pairs timed on the CPU oracle (-1 = auto, 0 = skip)")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary (other candidate mode) measurement")
     p.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (kernel timing off)")
@@ -83,7 +86,8 @@ class Workload:
         self.intr = O.scaled_intrinsics(rows, cols)
         self.mode_id = {"dense": V.CANDIDATES_DENSE, "c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO}[mode]
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(self.intr[:2], self.intr[2:4], self.intr[4]),
-                       candidates_mode=self.mode_id, huber_delta=args.huber)
+                       candidates_mode=self.mode_id, huber_delta=args.huber,
+                       arithmetic=V.ARITH_FUSED if args.arith == "fused" else V.ARITH_EXACT)
         if mode == "dso":
             seed0 |= 1 << 63  # piecewise-constant texture: the DSO thresholds reject the smooth texture entirely
         self.cfg = cfg
@@ -214,6 +218,7 @@ def main():
             "candidates": {"dense": "dense (all-true level-0 mask, extension)", "c2f": "coarse_to_fine (reference selection)",
                            "dso": "DSO-style selection (dso.rs, examples/candidates_dso.rs parameters)"}[args.candidates],
             "huber_delta": args.huber,
+            "arithmetic": args.arith,
             "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of poses per step" if world > 1 else "1 GPU",
             "launch": "hipGraph replay" if args.graph else "eager",
         },

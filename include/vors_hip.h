@@ -43,6 +43,15 @@ enum { VORS_ROW_MAJOR = 0, VORS_COL_MAJOR = 1 };
  *     counter-based hash instead of the reference's unseeded thread_rng. */
 enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1, VORS_CANDIDATES_DSO = 2 };
 
+/* Per-point arithmetic of the LM evaluation (f32 in both modes; integer stages, the inside test, the order of the sums and the LM
+ * control flow do not depend on it).
+ * 0 = EXACT: every per-point expression in the reference's evaluation order without FMA contraction — inverse depths, Jacobians
+ *     and per-point residuals are bit-identical to the reference's arithmetic (the parity anchor).
+ * 1 = FUSED: algebraically equivalent shorter forms (warp through the homography K R K^-1 plus _z K t with one hardware
+ *     reciprocal, lerp-form bilinear interpolation, factored Jacobian; FMA). Per-point values agree to a few ulp; poses agree with
+ *     EXACT to ~1e-6 and stay within the 1e-4 rad / 1e-4 m parity bar (tests/test_gpu_parity.py runs both). About twice as fast. */
+enum { VORS_ARITH_EXACT = 0, VORS_ARITH_FUSED = 1 };
+
 /* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
 enum { VORS_TRACK_OK = 0, VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT = 1 };
 
@@ -58,6 +67,7 @@ typedef struct vors_config {
     float idepth_variance;             /* Config::idepth_variance */
     int32_t candidates_mode;           /* extension: VORS_CANDIDATES_* */
     float huber_delta;                 /* extension: Huber threshold on |r| in grey levels; <= 0 = plain L2 (reference) */
+    int32_t arithmetic;                /* extension: VORS_ARITH_* (how the per-point f32 expressions are evaluated) */
 } vors_config;
 
 #define VORS_MAX_LEVELS 8
@@ -77,7 +87,7 @@ const char* vors_last_error(void);
 /* Number of visible HIP devices (0 when none / no runtime). Never fails. */
 int vors_device_count(void);
 /* ABI version of this header: bump on any signature change. */
-int vors_abi_version(void);
+int vors_abi_version(void);  /* 2: vors_config.arithmetic */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces
@@ -165,6 +175,12 @@ vors_status vors_batch_get_current_image(vors_batch* b, int pair, int level, uin
  * NOT the reference's column-major order: sort by (x, y) to compare. *n = number of usable candidates. */
 vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capacity, int32_t* xy, float* idepth, float* jac,
                                   uint8_t* tmpl, int* n);
+
+/* One evaluation — eval_energy + compute_eval_data (lm_optimizer.rs:68-107) — of level `level` of pair `pair` as the handle holds it
+ * after prepare_keyframes + track_current, at an explicit model (HOST pointer, 7 floats), in the given VORS_ARITH_* mode whatever the
+ * handle's own: sums29 (HOST) = sum r^2 (Huber loss with huber_delta), n_inside, g[6], H upper triangle row-wise [21]. Synchronises.
+ * This is the operator-level window on the tracker's own point sources; tests compare EXACT and FUSED through it. */
+vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const float model7[7], int arithmetic, float sums29[29]);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 3. Operator level — the optimizer trait's pieces for one pyramid level.  Replaces, for

@@ -26,13 +26,13 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(V.EXPORTED_SYMBOLS)
-    assert lib.vors_abi_version() == 1
+    assert lib.vors_abi_version() == 2   # 2: vors_config.arithmetic
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(V.vors_config) == 44
+    assert C.sizeof(V.vors_config) == 48
     assert C.sizeof(V.vors_pair_stats) == 7 * 4 + 4 + 4 + 3 * 8 * 4
-    assert C.sizeof(O.Config) == C.sizeof(V.vors_config)
+    assert C.sizeof(O.Config) == C.sizeof(V.vors_config) - 4   # the oracle has ONE arithmetic (the reference's): no `arithmetic` field
 
 
 def test_compute_entry_points_fail_loudly_without_gpu():

@@ -1,0 +1,162 @@
+"""The FUSED arithmetic mode (vors_config.arithmetic = VORS_ARITH_FUSED, include/vors_hip.h) against the oracle and against the EXACT
+mode. GPU only.
+
+EXACT evaluates every per-point expression in the reference's order (bit-identical residuals / Jacobians: tests/test_gpu_parity.py).
+FUSED computes the same quantities from algebraically equivalent shorter forms (warp through H = K R K^-1 and _z K t with a hardware
+reciprocal, lerp-form bilinear interpolation, factored Jacobian, FMA). The bar is the north star's: poses within 1e-4 rad / 1e-4 m of
+the reference arithmetic (the oracle), statuses / candidate counts / masks identical (integer stages do not depend on the mode).
+FUSED-vs-EXACT differences are printed; they are of the size of the summation-order effect (tests/test_oracle_sensitivity.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vors_amd as V
+from oracle import oracle as O
+
+POSE_TOL = 1e-4
+BLOCKY = 1 << 63
+
+
+def vcfg(L, intr, mode, arith, huber=0.0, thresh=7):
+    return V.Config(nb_levels=L, candidates_diff_threshold=thresh, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]),
+                    candidates_mode=mode, huber_delta=huber, arithmetic=arith)
+
+
+def run(cfg, kg, kd, cg):
+    import torch
+    n, rows, cols = kg.shape
+    b = V.Batch(cfg, n, rows, cols)
+    t = [torch.from_numpy(np.ascontiguousarray(kg)).cuda(), torch.from_numpy(np.ascontiguousarray(kd).view(np.int16)).cuda(),
+         torch.from_numpy(np.ascontiguousarray(cg)).cuda()]
+    poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    stats = V.stats_tensor(n)
+    b.track_pairs(*t, poses, status, stats)
+    torch.cuda.synchronize()
+    return poses.cpu().numpy(), status.cpu().numpy(), V.decode_stats(stats)
+
+
+@pytest.mark.parametrize("rows,cols,L,n,mode,huber", [
+    (120, 160, 4, 16, 1, 0.0), (240, 320, 5, 8, 1, 0.0), (480, 640, 6, 6, 1, 0.0), (101, 135, 3, 4, 1, 0.0), (66, 130, 2, 3, 1, 0.0),
+    (384, 512, 8, 2, 1, 0.0), (97, 131, 3, 6, 1, 8.0), (240, 320, 5, 6, 1, 10.0),
+    (120, 160, 4, 16, 0, 0.0), (480, 640, 6, 6, 0, 0.0), (97, 131, 3, 6, 0, 8.0), (64, 64, 1, 2, 0, 0.0),
+    (240, 320, 5, 3, 2, 0.0), (120, 160, 4, 3, 2, 0.0)])
+def test_fused_vs_oracle_and_exact(rows, cols, L, n, mode, huber):
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, _, _ = O.synth_batch(n, rows, cols, seed0=(BLOCKY if mode == 2 else 0) | (0x5EEDF500 + rows), intr=intr)
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode, huber_delta=huber), kg, kd, cg, n_threads=8)
+    pe, se, ste = run(vcfg(L, intr, mode, V.ARITH_EXACT, huber), kg, kd, cg)
+    pf, sf, stf = run(vcfg(L, intr, mode, V.ARITH_FUSED, huber), kg, kd, cg)
+    assert (sf == ref["status"]).all() and (se == ref["status"]).all()
+    assert (stf["n_points"][:, :L] == ref["n_points"]).all()
+    ok = ref["status"] == 0
+    ef = np.abs(pf - ref["poses"]).max(axis=1)
+    ee = np.abs(pe - ref["poses"]).max(axis=1)
+    fe = np.abs(pf - pe).max(axis=1)
+    print(f"[{cols}x{rows} L{L} mode{mode} huber{huber}] vs oracle: fused {ef[ok].max():.2e} exact {ee[ok].max():.2e}; fused vs exact {fe[ok].max():.2e}")
+    assert (ef[ok] < POSE_TOL).all(), f"fused pose error vs oracle {ef}"
+    assert (pf[~ok] == ref["poses"][~ok]).all()
+    assert np.abs(stf["optical_flow"][ok] - ref["flow"][ok]).max() < 1e-3
+
+
+def test_fused_negative_focal_and_skew():
+    rows, cols, L = 96, 128, 3
+    intr = (63.4, 47.3, 96.2, -96.0, 0.3)   # negative fv like INTRINSICS_ICL_NUIM (tum_rgbd.rs:25), non-zero skew
+    kg, kd, cg, _, _ = O.synth_batch(4, rows, cols, seed0=0x5EED9000, intr=O.scaled_intrinsics(rows, cols))
+    for mode in (0, 1):
+        ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg, kd, cg)
+        pf, sf, _ = run(vcfg(L, intr, mode, V.ARITH_FUSED), kg, kd, cg)
+        assert (sf == ref["status"]).all()
+        ok = sf == 0
+        assert ok.any() and np.abs(pf[ok] - ref["poses"][ok]).max() < POSE_TOL
+
+
+def test_fused_degenerate_inputs():
+    """No depth at all, flat images, depth 1 / 65535: the same statuses as the oracle, untouched poses, no NaN leaking into a pose."""
+    rows, cols, L = 64, 96, 3
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, _, _ = O.synth_batch(4, rows, cols, seed0=0x5EED8000, intr=intr)
+    kd[0] = 0
+    kg[1] = 128
+    cg[1] = 128
+    kd[2] = 65535
+    kd[3] = 1
+    for mode in (0, 1):
+        ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg, kd, cg)
+        pf, sf, stf = run(vcfg(L, intr, mode, V.ARITH_FUSED), kg, kd, cg)
+        assert (sf == ref["status"]).all(), (mode, sf, ref["status"])
+        assert np.isfinite(pf).all()
+        bad = sf != 0
+        assert (pf[bad] == ref["poses"][bad]).all()
+        assert (stf["n_points"][:, :L] == ref["n_points"]).all()
+
+
+def test_fused_full_size_statistics_and_determinism():
+    import torch
+    rows, cols, L = 480, 640, 6
+    intr = O.scaled_intrinsics(rows, cols)
+    for mode, n in ((1, 48), (0, 192)):
+        kg, kd, cg, _, gt = V.synth_render_pairs(0x5EEDC000, n, rows, cols, intr)
+        out = []
+        for arith in (V.ARITH_FUSED, V.ARITH_FUSED, V.ARITH_EXACT):
+            b = V.Batch(vcfg(L, intr, mode, arith), n, rows, cols)
+            poses = torch.zeros((n, 7), device="cuda")
+            status = torch.zeros(n, dtype=torch.int32, device="cuda")
+            stats = V.stats_tensor(n)
+            b.track_pairs(kg, kd, cg, poses, status, stats)
+            torch.cuda.synchronize()
+            out.append((poses.cpu().numpy(), status.cpu().numpy(), V.decode_stats(stats)))
+        assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all(), "fused mode must be deterministic"
+        ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg.cpu().numpy(), kd.cpu().numpy().view(np.uint16),
+                            cg.cpu().numpy(), n_threads=os.cpu_count() or 1)
+        err = np.abs(out[0][0] - ref["poses"]).max(axis=1)
+        fe = np.abs(out[0][0] - out[2][0]).max(axis=1)
+        flips = (out[0][2]["nb_iter"][:, :L] != ref["nb_iter"]).any(axis=1).mean()
+        print(f"mode {mode}: fused vs oracle max {err.max():.2e} p99 {np.quantile(err, 0.99):.2e}; fused vs exact max {fe.max():.2e}; "
+              f"branch-flip rate vs oracle {flips:.0%}")
+        assert (out[0][1] == ref["status"]).all()
+        assert err.max() < POSE_TOL and np.quantile(err, 0.99) < 3e-5
+        gt_pose = np.stack([O.iso_inverse(m) for m in gt.cpu().numpy()])
+        assert np.median(np.abs(out[0][0] - gt_pose).max(axis=1)) < 3e-3
+
+
+@pytest.mark.parametrize("env", [{"VORS_LM_SPLIT": "0"}, {"VORS_LM_SPLIT_ROUNDS": "1"}, {"VORS_LM_SPLIT_ROUNDS": "3"},
+                                 {"VORS_LM_SPLIT_LEVELS": "1"}, {"VORS_LM_SPLIT_LEVELS": "3", "VORS_LM_CHUNKS": "7"}],
+                         ids=["monolithic", "rounds1", "rounds3", "one_split_level", "three_split_levels_odd_chunks"])
+def test_fused_dense_scheduling_variants(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rows, cols, L, n = 240, 320, 5, 12
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, _, _ = O.synth_batch(n, rows, cols, seed0=0x5EED7700, intr=intr, motion_scale=2.0)
+    kd[3] = 0
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=1), kg, kd, cg, n_threads=8)
+    pf, sf, stf = run(vcfg(L, intr, 1, V.ARITH_FUSED), kg, kd, cg)
+    assert (sf == ref["status"]).all()
+    ok = sf == 0
+    assert np.abs(pf[ok] - ref["poses"][ok]).max() < POSE_TOL
+    assert (pf[~ok] == ref["poses"][~ok]).all()
+    assert ((stf["nb_iter"][ok][:, :L] >= 1) & (stf["nb_iter"][ok][:, :L] <= 21)).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fused_tracker_sequence(mode):
+    rows, cols, L = 120, 160, 4
+    intr = O.scaled_intrinsics(rows, cols)
+    step = np.array([0.012, -0.006, 0.004, 0.002, -0.003, 0.001])
+    seed = (BLOCKY | 77) if mode == 2 else 77
+    frames = [O.synth_frame(seed, step * k, rows, cols, intr, frame_salt=k) for k in range(12)]
+    ot = O.Tracker(O.make_config(L, intr, candidates_mode=mode), 0.0, frames[0][1], 0.0, frames[0][0])
+    vt = vcfg(L, intr, mode, V.ARITH_FUSED).init(0.0, frames[0][1], 0.0, frames[0][0])
+    switches = 0
+    for k in range(1, len(frames)):
+        g, d = frames[k]
+        assert ot.track(0.1 * k, d, 0.1 * k, g) == vt.track(0.1 * k, d, 0.1 * k, g)
+        assert np.abs(ot.current_frame()[1] - vt.current_frame()[1]).max() < POSE_TOL, f"frame {k}"
+        assert ot.last()["changed_keyframe"] == bool(vt.last_stats()["change_keyframe"])
+        switches += int(ot.last()["changed_keyframe"])
+    assert switches >= 1

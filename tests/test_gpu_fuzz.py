@@ -28,8 +28,9 @@ def _cases():
     return out
 
 
+@pytest.mark.parametrize("arith", [V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
 @pytest.mark.parametrize("i,rows,cols,L,mode,huber", _cases(), ids=lambda v: str(v))
-def test_random_shapes_vs_oracle(i, rows, cols, L, mode, huber):
+def test_random_shapes_vs_oracle(i, rows, cols, L, mode, huber, arith):
     import torch
     rng = np.random.default_rng(1000 + i)
     intr = list(O.scaled_intrinsics(rows, cols))
@@ -41,7 +42,8 @@ def test_random_shapes_vs_oracle(i, rows, cols, L, mode, huber):
     n = 3
     kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=seed0, intr=tuple(intr), motion_scale=float(rng.uniform(0.3, 1.5)))
     ref = O.track_pairs(O.make_config(L, tuple(intr), candidates_mode=mode, huber_delta=huber), kg, kd, cg)
-    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(tuple(intr[:2]), tuple(intr[2:4]), intr[4]), candidates_mode=mode, huber_delta=huber)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(tuple(intr[:2]), tuple(intr[2:4]), intr[4]), candidates_mode=mode, huber_delta=huber,
+                   arithmetic=arith)
     b = V.Batch(cfg, n, rows, cols)
     t = [torch.from_numpy(np.ascontiguousarray(kg)).cuda(), torch.from_numpy(np.ascontiguousarray(kd).view(np.int16)).cuda(),
          torch.from_numpy(np.ascontiguousarray(cg)).cuda()]

@@ -57,7 +57,10 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
         return fail(VORS_ERR_INVALID_ARGUMENT, "candidates_diff_threshold must fit u16");
     std::memset(g, 0, sizeof(*g));
     g->L = cfg->nb_levels;
+    if (cfg->arithmetic != VORS_ARITH_EXACT && cfg->arithmetic != VORS_ARITH_FUSED)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
     g->mode = cfg->candidates_mode;
+    g->arith = cfg->arithmetic;
     g->thresh = cfg->candidates_diff_threshold;
     g->depth_scale = cfg->depth_scale;
     g->idepth_variance = cfg->idepth_variance;
@@ -203,7 +206,7 @@ int vors_device_count(void) {
     }
     return n;
 }
-int vors_abi_version(void) { return 1; }
+int vors_abi_version(void) { return 2; }
 
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
     if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -549,6 +552,28 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
         ++cnt;
     }
     *n_out = cnt;
+    return VORS_OK;
+}
+
+vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const float model7[7], int arithmetic, float sums29[29]) {
+    if (!b || !model7 || !sums29) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (pair < 0 || pair >= b->prepared_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
+    if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
+    if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED) return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
+    if (arithmetic == VORS_ARITH_FUSED && b->g.mode != VORS_CANDIDATES_DENSE)
+        return fail(VORS_ERR_UNSUPPORTED, "fused arithmetic is implemented for the dense candidate mode");
+    DevBuf d_model, d_out;
+    HIP_TRY(d_model.alloc(7 * sizeof(float)));
+    HIP_TRY(d_out.alloc(32 * sizeof(float)));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(d_model.p, model7, 7 * sizeof(float), hipMemcpyHostToDevice));
+    const Pyramid cur{b->cur_level0, b->cur_upper}, kf{b->kf_level0, b->kf_upper};
+    if (arithmetic == VORS_ARITH_FUSED)
+        launch_lm_eval_level_fused(b->g, cur, kf, b->kf_depth, b->rec, pair, level, d_model.as<float>(), d_out.as<float>(), nullptr);
+    else
+        launch_lm_eval_level_exact(b->g, cur, kf, b->kf_depth, b->rec, pair, level, d_model.as<float>(), d_out.as<float>(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(sums29, d_out.p, 29 * sizeof(float), hipMemcpyDeviceToHost));
     return VORS_OK;
 }
 

@@ -22,6 +22,7 @@ struct LevelGeom {
 struct Geom {
     int L;              // nb_levels
     int mode;           // VORS_CANDIDATES_*
+    int arith;          // VORS_ARITH_*
     int thresh;         // candidates_diff_threshold (u16)
     float depth_scale, idepth_variance, huber_delta;
     int S0;             // rows*cols of level 0 (pair stride of level-0 images and depth maps)
@@ -127,6 +128,16 @@ void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const 
 // `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).
 void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
                      float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
+// the two arithmetic modes of the above (lm_kernels.hip compiled with VORS_FUSED = 0 / 1)
+void launch_lm_track_exact(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
+                           float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
+void launch_lm_track_fused(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
+                           float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
+// One evaluation of one level of one pair of a prepared batch at an explicit model, per arithmetic mode -> 29 sums.
+void launch_lm_eval_level_exact(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
+                                const float* model7, float* out29, hipStream_t s);
+void launch_lm_eval_level_fused(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
+                                const float* model7, float* out29, hipStream_t s);
 // Operator level on explicit observations of one level (device buffers): eval at `model` -> out29 partial sums layout:
 // [0]=sum r^2 (or Huber loss), [1]=n_inside (as float), [2..7]=g, [8..28]=H upper triangle row-wise.
 void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,

@@ -23,7 +23,18 @@
 #include "device_common.h"
 #include "engine.h"
 
+// This file is compiled twice (csrc/Makefile): VORS_FUSED=0 -> lm_kernels.o, the EXACT arithmetic (the reference's evaluation order per
+// point, bit-identical residuals / Jacobians; parity anchor; also holds the operator-level kernels), and VORS_FUSED=1 ->
+// lm_kernels_fused.o, the FUSED arithmetic (vors_config.arithmetic = VORS_ARITH_FUSED): the same quantities from algebraically
+// equivalent, shorter expressions — see "fused arithmetic" below. Kernels carry the mode as a template argument, so both objects link
+// into one library.
+#ifndef VORS_FUSED
+#define VORS_FUSED 0
+#endif
+
 namespace vors {
+
+constexpr bool kFused = VORS_FUSED != 0;
 
 #define NACC 29
 #define LM_MAX_WAVES 16
@@ -52,6 +63,7 @@ struct Pos {
 
 // ---- point source: stored record planes (sparse mode, operator level). G = 2 slots (i, i + BLOCK).
 struct RecSrc {
+    static constexpr bool FUSED = false;
     static constexpr int G = 2;
     static constexpr bool PREFETCH = false;
     static constexpr bool SKIP_EMPTY = true;
@@ -109,6 +121,7 @@ struct RecSrc {
 // DenseSrc: one pixel per unit, any image width (fallback, keyframe test, diagnostics).
 template <bool LEVEL0>
 struct DenseSrc {
+    static constexpr bool FUSED = false;
     static constexpr int G = 1;
     static constexpr bool PREFETCH = false;
     static constexpr bool SKIP_EMPTY = false;
@@ -182,6 +195,7 @@ struct DenseSrc {
 // row and plane instead of ~8 byte loads per pixel: coalesced 256 B - 1 KiB per wavefront instruction, 4-way ILP per lane.
 template <bool LEVEL0, bool FAST>
 struct DenseQuadSrc {
+    static constexpr bool FUSED = false;
     static constexpr int G = 4;
     static constexpr bool PREFETCH = false;
     static constexpr bool SKIP_EMPTY = false;
@@ -398,6 +412,249 @@ __device__ __forceinline__ Iso iso_uniform(const Iso& m) {
     return Iso{V3{uniform_f(m.t.x), uniform_f(m.t.y), uniform_f(m.t.z)}, Quat{uniform_f(m.q.i), uniform_f(m.q.j), uniform_f(m.q.k), uniform_f(m.q.w)}};
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// FUSED ARITHMETIC (vors_config.arithmetic = VORS_ARITH_FUSED).  Same quantities, shorter expressions, f32 throughout.
+//
+//  warp (lm_optimizer.rs:213-219 = back_project, Iso3 * point, project, / z): with P = z K^-1 (x, y, 1)^T,
+//      (pu, pv, pz) / z = K R K^-1 (x, y, 1)^T + _z K t = H (x, y, 1)^T + _z m,      u = pu / pz, v = pv / pz
+//    H (3x3) and m (3) are uniform per evaluation (formed once, in f64, from the model); H (x, y, 1)^T is affine in the pixel, so a
+//    point costs 3 additions + 3 FMAs + one reciprocal + 2 multiplications instead of a quaternion rotation, two projections and
+//    four divisions. The reciprocal is v_rcp_f32 (1 ulp): u, v carry ~1.5 ulp instead of the ~3-4 ulp the reference's own chain
+//    accumulates.
+//  interpolate (lm_optimizer.rs:236-247): two horizontal lerps + one vertical lerp (6 FMA-class ops instead of 4 triple products).
+//  warp_jacobian_at (inverse_compositional.rs:313-341): the six entries are linear in (gu, gv) with coefficients that depend on the
+//    pixel only through a = x - cu, b = y - cv and c' = c / (fu fv); the per-row parts are shared by the pixels of a quad.
+//  level-0 inverse depth: scale * rcp(depth) instead of a division (or a table).
+//  The inside test, the integer gradients / masks, the order of the 29 sums and the whole LM control flow are unchanged.
+//  Gate: tests/test_gpu_parity.py runs every configuration in both modes: FUSED vs oracle <= 1e-4 (the north-star tolerance) and
+//  FUSED vs EXACT reported.
+// ------------------------------------------------------------------------------------------------------------
+struct FusedCtx {  // uniform per evaluation, kept in scalar registers
+    float h00, h01, h02, h10, h11, h12, h20, h21, h22;  // H = K R K^-1
+    float m0, m1, m2;                                   // m = K t
+    float h00_2, h00_3, h10_2, h10_3, h20_2, h20_3;     // 2x / 3x the first column: pixels x0+2, x0+3 of a quad
+};
+__device__ __forceinline__ FusedCtx make_fused_ctx(const Intr& k, const Iso& m) {
+    const double qi = m.q.i, qj = m.q.j, qk = m.q.k, qw = m.q.w;
+    // R = I + 2 w [q]x + 2 [q]x^2: the matrix of nalgebra's UnitQuaternion * Vector3 (lie.h quat_rotate), no unit-norm assumption
+    const double r00 = 1.0 - 2.0 * (qj * qj + qk * qk), r01 = 2.0 * (qi * qj - qk * qw), r02 = 2.0 * (qi * qk + qj * qw);
+    const double r10 = 2.0 * (qi * qj + qk * qw), r11 = 1.0 - 2.0 * (qi * qi + qk * qk), r12 = 2.0 * (qj * qk - qi * qw);
+    const double r20 = 2.0 * (qi * qk - qj * qw), r21 = 2.0 * (qj * qk + qi * qw), r22 = 1.0 - 2.0 * (qi * qi + qj * qj);
+    const double fu = k.fu, fv = k.fv, sk = k.skew, cu = k.cu, cv = k.cv;
+    // K R (camera.rs:126-132)
+    const double a00 = fu * r00 + sk * r10 + cu * r20, a01 = fu * r01 + sk * r11 + cu * r21, a02 = fu * r02 + sk * r12 + cu * r22;
+    const double a10 = fv * r10 + cv * r20, a11 = fv * r11 + cv * r21, a12 = fv * r12 + cv * r22;
+    // ... K^-1 (camera.rs:135-140): col0 = A0 / fu, col1 = (A1 - s col0) / fv, col2 = A2 - cu col0 - cv col1
+    const double h00 = a00 / fu, h10 = a10 / fu, h20 = r20 / fu;
+    const double h01 = (a01 - sk * h00) / fv, h11 = (a11 - sk * h10) / fv, h21 = (r21 - sk * h20) / fv;
+    const double h02 = a02 - cu * h00 - cv * h01, h12 = a12 - cu * h10 - cv * h11, h22 = r22 - cu * h20 - cv * h21;
+    const double tx = m.t.x, ty = m.t.y, tz = m.t.z;
+    FusedCtx f;
+    f.h00 = uniform_f((float)h00); f.h01 = uniform_f((float)h01); f.h02 = uniform_f((float)h02);
+    f.h10 = uniform_f((float)h10); f.h11 = uniform_f((float)h11); f.h12 = uniform_f((float)h12);
+    f.h20 = uniform_f((float)h20); f.h21 = uniform_f((float)h21); f.h22 = uniform_f((float)h22);
+    f.m0 = uniform_f((float)(fu * tx + sk * ty + cu * tz));
+    f.m1 = uniform_f((float)(fv * ty + cv * tz));
+    f.m2 = uniform_f((float)tz);
+    f.h00_2 = uniform_f((float)(2.0 * h00)); f.h00_3 = uniform_f((float)(3.0 * h00));
+    f.h10_2 = uniform_f((float)(2.0 * h10)); f.h10_3 = uniform_f((float)(3.0 * h10));
+    f.h20_2 = uniform_f((float)(2.0 * h20)); f.h20_3 = uniform_f((float)(3.0 * h20));
+    return f;
+}
+// Workgroup-uniform: would this model move some pixel by less than ~1e-2 px?  (|rotation| <= 1e-5 rad, |t| <= 1e-6 m.)
+__device__ __forceinline__ bool model_near_identity(const Iso& m) {
+    const float r = fmaxf(fmaxf(fabsf(m.q.i), fabsf(m.q.j)), fabsf(m.q.k)), t = fmaxf(fmaxf(fabsf(m.t.x), fabsf(m.t.y)), fabsf(m.t.z));
+    return __builtin_amdgcn_readfirstlane((r <= 5e-6f && t <= 1e-6f) ? 1 : 0) != 0;
+}
+struct JacK {  // level constants of the Jacobian, uniform
+    float fu, fv, s, cu, cv, inv_fu, inv_fv, s_fuv;
+};
+__device__ __forceinline__ JacK make_jack(const Intr& k) {
+    JacK j;
+    j.fu = k.fu; j.fv = k.fv; j.s = k.skew; j.cu = k.cu; j.cv = k.cv;
+    j.inv_fu = uniform_f((float)(1.0 / (double)k.fu));
+    j.inv_fv = uniform_f((float)(1.0 / (double)k.fv));
+    j.s_fuv = uniform_f((float)((double)k.skew / ((double)k.fu * (double)k.fv)));
+    return j;
+}
+// One candidate, ready for the fused evaluation.
+struct FPt {
+    float bu, bv, bz;  // H (x, y, 1)^T
+    float a, b;        // x - cu, y - cv
+    float iz;          // inverse depth; 0 for a pixel that is not a candidate (keeps every product finite)
+    float tm;          // template grey level
+    float gu, gv;      // integer gradients as floats (zero on the level-0 border), unused by energy-only evaluations
+    bool valid;
+};
+__device__ __forceinline__ Warped fused_warp(const ImgCtx& c, const FusedCtx& f, const FPt& p) {
+    Warped w;
+    const float hz = fmaf(f.m2, p.iz, p.bz), hu = fmaf(f.m0, p.iz, p.bu), hv = fmaf(f.m1, p.iz, p.bv);
+    const float rz = __builtin_amdgcn_rcpf(hz);
+    w.u = hu * rz;
+    w.v = hv * rz;
+    w.uf = floorf(w.u);
+    w.vf = floorf(w.v);
+    // the reference's strict test (lm_optimizer.rs:227-231); NaN / inf coordinates compare false -> outside
+    w.inside = p.valid && (w.uf >= 0.f) && (w.uf < (float)(c.cols - 2)) && (w.vf >= 0.f) && (w.vf < (float)(c.rows - 2));
+    w.off = (__float2int_rz(w.vf) * c.cols + __float2int_rz(w.uf)) & (w.inside ? -1 : 0);
+    return w;
+}
+// Fused residual + sums of one point. `cnt` is the lane's integer count of inside points (one add-with-carry; replaces sum 1).
+template <bool HUBER, bool ENERGY_ONLY>
+__device__ __forceinline__ void fused_accumulate(const ImgCtx& c, const JacK& k, const FPt& p, const Warped& w, const Taps& t,
+                                                 float acc[NACC], int& cnt) {
+    const float t00 = (float)(t.top & 0xff), t01 = (float)(t.top >> 8), t10 = (float)(t.bot & 0xff), t11 = (float)(t.bot >> 8);
+    const float fa = w.u - w.uf, fb = w.v - w.vf;
+    const float top = fmaf(fa, t01 - t00, t00), bot = fmaf(fa, t11 - t10, t10);
+    const float im = fmaf(fb, bot - top, top);
+    const float r = w.inside ? im - p.tm : 0.f;  // selected, never multiplied: an outside point contributes exactly nothing
+    cnt += w.inside ? 1 : 0;
+    float wgt = 1.0f, wr = r;
+    if (HUBER) {  // extension (not in the reference)
+        const float ar = fabsf(r);
+        const bool lin = ar > c.huber;
+        acc[0] += lin ? c.huber * fmaf(2.0f, ar, -c.huber) : r * r;
+        wgt = lin ? c.huber * __builtin_amdgcn_rcpf(ar) : 1.0f;
+        wr = wgt * r;
+    } else {
+        acc[0] = fmaf(r, r, acc[0]);
+    }
+    if (ENERGY_ONLY) return;
+    // warp_jacobian_at (inverse_compositional.rs:313-341), linear in (gu, gv); an outside point gets gu = gv = 0 -> J = 0
+    const float gu = w.inside ? p.gu : 0.f, gv = w.inside ? p.gv : 0.f;
+    const float b_fv = p.b * k.inv_fv;                              // per row
+    const float cp = fmaf(p.a, k.inv_fu, -(p.b * k.s_fuv));          // c' = c / (fu fv), c = a fv - s b
+    const float q3 = fmaf(-p.b, b_fv, -k.fv);                        // per row
+    const float p3 = fmaf(-p.a, b_fv, -k.s);
+    const float p4 = fmaf(p.a, cp, k.fu), q4 = p.b * cp;
+    const float p5 = fmaf(k.s, cp, -(k.fu * b_fv)), q5 = cp * k.fv;
+    float J[6];
+    J[0] = (gu * k.fu) * p.iz;
+    J[1] = fmaf(gu, k.s, gv * k.fv) * p.iz;
+    J[2] = -(fmaf(gu, p.a, gv * p.b) * p.iz);
+    J[3] = fmaf(gu, p3, gv * q3);
+    J[4] = fmaf(gu, p4, gv * q4);
+    J[5] = fmaf(gu, p5, gv * q5);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q], wr, acc[2 + q]);
+    int h = 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float jq = HUBER ? wgt * J[q] : J[q];
+#pragma unroll
+        for (int s = q; s < 6; ++s) {
+            acc[h] = fmaf(jq, J[s], acc[h]);
+            ++h;
+        }
+    }
+}
+
+// Fused point sources: the exact sources' loads, decoded into FPt.
+template <bool LEVEL0>
+struct FusedPixSrc : DenseSrc<LEVEL0> {  // one pixel per unit, any width
+    using Base = DenseSrc<LEVEL0>;
+    static constexpr bool FUSED = true;
+    template <bool ENERGY_ONLY>
+    __device__ __forceinline__ void fpoints(const typename Base::Raw& r, const FusedCtx& f, FPt p[1]) const {
+        const float xf = (float)r.x, yf = (float)r.y;
+        p[0].bu = fmaf(f.h00, xf, fmaf(f.h01, yf, f.h02));
+        p[0].bv = fmaf(f.h10, xf, fmaf(f.h11, yf, f.h12));
+        p[0].bz = fmaf(f.h20, xf, fmaf(f.h21, yf, f.h22));
+        p[0].a = xf - this->k.cu;
+        p[0].b = yf - this->k.cv;
+        p[0].valid = r.valid;
+        p[0].iz = r.valid ? r.izv : 0.f;
+        p[0].tm = (float)r.tm;
+        p[0].gu = (float)r.gx;
+        p[0].gv = (float)r.gy;
+    }
+};
+template <bool LEVEL0>
+struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjacent pixels per unit
+    using Base = DenseQuadSrc<LEVEL0, false>;
+    static constexpr bool FUSED = true;
+    using Raw = typename Base::Loaded;  // decoded straight into FPt
+    float depth_scale;
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const typename Base::Cursor& c, int, Raw& r) const {
+        this->load(c, r);
+    }
+    template <bool ENERGY_ONLY>
+    __device__ __forceinline__ void fpoints(const Raw& l, const FusedCtx& f, FPt p[4]) const {
+        const float x0f = (float)l.x0, yf = (float)l.y;
+        const float bu0 = fmaf(f.h00, x0f, fmaf(f.h01, yf, f.h02));
+        const float bv0 = fmaf(f.h10, x0f, fmaf(f.h11, yf, f.h12));
+        const float bz0 = fmaf(f.h20, x0f, fmaf(f.h21, yf, f.h22));
+        const float a0 = x0f - this->kf.k.cu, b = yf - this->kf.k.cv;
+        p[0].bu = bu0; p[1].bu = bu0 + f.h00; p[2].bu = bu0 + f.h00_2; p[3].bu = bu0 + f.h00_3;
+        p[0].bv = bv0; p[1].bv = bv0 + f.h10; p[2].bv = bv0 + f.h10_2; p[3].bv = bv0 + f.h10_3;
+        p[0].bz = bz0; p[1].bz = bz0 + f.h20; p[2].bz = bz0 + f.h20_2; p[3].bz = bz0 + f.h20_3;
+        int tm[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tm[j] = (l.cw >> (8 * j)) & 0xff;
+            p[j].tm = (float)tm[j];
+            p[j].a = a0 + (float)j;
+            p[j].b = b;
+        }
+        const int rows = this->rows, cols = this->cols;
+        if (LEVEL0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t dz = (j < 2 ? (l.d0 >> (16 * j)) : (l.d1 >> (16 * (j - 2)))) & 0xffffu;
+                p[j].valid = dz != 0;
+                // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); 0 for an unknown depth
+                p[j].iz = p[j].valid ? depth_scale * __builtin_amdgcn_rcpf((float)dz) : 0.f;
+            }
+            if (!ENERGY_ONLY) {  // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33): integer, exact
+                const int yin = (l.y > 0 && l.y < rows - 1) ? -1 : 0;
+                const int bb[6] = {(int)l.w3, tm[0], tm[1], tm[2], tm[3], (int)l.w4};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = l.x0 + j;
+                    const int in = yin & ((x > 0 && x < cols - 1) ? -1 : 0);
+                    const int up = (l.w1 >> (8 * j)) & 0xff, dn = (l.w2 >> (8 * j)) & 0xff;
+                    p[j].gu = (float)(half_trunc(bb[j + 2] - bb[j]) & in);
+                    p[j].gv = (float)(half_trunc(dn - up) & in);
+                }
+            }
+        } else {
+            const uint32_t zz[4] = {l.d0, l.d1, l.d2, l.d3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = __int_as_float((int)zz[j]);
+                p[j].valid = !(z != z);
+                p[j].iz = p[j].valid ? z : 0.f;
+                if (!ENERGY_ONLY) {  // 2x2 block gradients of the next finer level (gradient.rs:74-93): integer, exact
+                    const uint32_t w0 = j < 2 ? l.w1 : l.w2, w1 = j < 2 ? l.w3 : l.w4;
+                    const int sh = (j & 1) * 16;
+                    const int a = (w0 >> sh) & 0xff, cc = (w0 >> (sh + 8)) & 0xff;
+                    const int b2 = (w1 >> sh) & 0xff, d = (w1 >> (sh + 8)) & 0xff;
+                    p[j].gu = (float)half_trunc(cc + d - a - b2);
+                    p[j].gv = (float)half_trunc(b2 - a + d - cc);
+                }
+            }
+        }
+    }
+};
+
+// The fused per-group body: all points warped, all taps in flight, then the sums.
+template <bool HUBER, bool ENERGY_ONLY, class Src>
+__device__ __forceinline__ void process_group_fused(const Src& src, const typename Src::Raw& raw, const ImgCtx& c, const FusedCtx& f,
+                                                    const JacK& k, float acc[NACC], int& cnt) {
+    constexpr int G = Src::G;
+    FPt p[G];
+    src.template fpoints<ENERGY_ONLY>(raw, f, p);
+    Warped w[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) w[g] = fused_warp(c, f, p[g]);
+    Taps t[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t[g] = load_taps(c, w[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) fused_accumulate<HUBER, ENERGY_ONLY>(c, k, p[g], w[g], t[g], acc, cnt);
+}
+
 // The per-group body shared by both loop shapes: warp all G points, issue all taps, then Jacobians + sums two points at a
 // time (keeps the live Jacobian registers at 12 while the tap loads are in flight).
 template <bool HUBER, bool WRITE_RES, bool ENERGY_ONLY, class Src>
@@ -445,7 +702,28 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
                                                 float* residuals, int first = 0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
-    if constexpr (Src::PREFETCH) {
+    if constexpr (Src::FUSED) {
+        static_assert(!WRITE_RES, "per-point residuals are an operator-level (exact arithmetic) output");
+        // A (near-)identity model — every pair's first evaluation, and the first one after a keyframe switch — puts EVERY point on
+        // (or within rounding of) integer coordinates, where the reference's own rounding decides on which side of the strict inside
+        // test (lm_optimizer.rs:227-231) the border rows / columns fall: 1-3 % of the points at the coarsest level, and with them the
+        // first energy and the path of the whole LM loop. Only the reference's evaluation order reproduces that, so such an
+        // evaluation runs in the exact arithmetic (a handful per pair, mostly at the coarsest level).
+        if (model_near_identity(model)) {
+            eval_accumulate<BLOCK, HUBER, false, typename Src::Base, ENERGY_ONLY>(static_cast<const typename Src::Base&>(src), n_units, c, model, acc,
+                                                                               nullptr, first);
+            return;
+        }
+        const FusedCtx f = make_fused_ctx(c.k, model);
+        const JacK jk = make_jack(c.k);
+        int cnt = 0;  // inside points seen by this lane
+        for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
+            typename Src::Raw raw;
+            src.template fetch<BLOCK>(cur, n_units, raw);
+            process_group_fused<HUBER, ENERGY_ONLY>(src, raw, c, f, jk, acc, cnt);
+        }
+        acc[1] = (float)cnt;
+    } else if constexpr (Src::PREFETCH) {
         typename Src::Cursor cur = src.template begin<BLOCK>(first);
         if (cur.i >= n_units) return;
         typename Src::Loaded ld;
@@ -635,11 +913,35 @@ __device__ __forceinline__ void split_append(const LmSplitWs& ws, int round, boo
 // Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
 // ------------------------------------------------------------------------------------------------------------
 // Per-level dispatch: build the point source of a level and run `f(src, n_slots)`.
-template <bool DENSE, bool QUADS, class F>
+template <bool DENSE, bool QUADS, bool FUSED, class F>
 __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pair, const uint8_t* kf0, const uint8_t* kfu,
                                                   const uint16_t* kf_depth, const Records& rec, F&& f) {
     const LevelGeom lg = g.lv[lvl];
-    if constexpr (DENSE) {
+    if constexpr (DENSE && FUSED) {
+        const uint8_t* kimg = level_ptr(g, kf0, kfu, pair, lvl);
+        const uint8_t* kfine = lvl > 0 ? level_ptr(g, kf0, kfu, pair, lvl - 1) : nullptr;
+        const uint16_t* depth = kf_depth + (size_t)pair * g.S0;
+        const float* iz = lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr;
+        const int fcols = lvl > 0 ? g.lv[lvl - 1].cols : 0;
+        const bool quad_ok = QUADS && g.wide_loads_ok && (lg.cols % 4 == 0) && (lvl == 0 ? (g.S0 % 4 == 0) : (fcols % 8 == 0));
+        if (lvl == 0) {
+            if (quad_ok) {
+                FusedQuadSrc<true> src{{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT}, g.depth_scale};
+                f(src, lg.rows * (lg.cols / 4));
+            } else {
+                FusedPixSrc<true> src{{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.k, g.depth_scale}};
+                f(src, lg.n_slots);
+            }
+        } else {
+            if (quad_ok) {
+                FusedQuadSrc<false> src{{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.cols / 4, IntrFast{lg.k, lg.fu, lg.fv}, rec.LUT}, g.depth_scale};
+                f(src, lg.rows * (lg.cols / 4));
+            } else {
+                FusedPixSrc<false> src{{kimg, kfine, depth, iz, lg.rows, lg.cols, fcols, lg.k, g.depth_scale}};
+                f(src, lg.n_slots);
+            }
+        }
+    } else if constexpr (DENSE) {
         const uint8_t* kimg = level_ptr(g, kf0, kfu, pair, lvl);
         const uint8_t* kfine = lvl > 0 ? level_ptr(g, kf0, kfu, pair, lvl - 1) : nullptr;
         const uint16_t* depth = kf_depth + (size_t)pair * g.S0;
@@ -688,7 +990,7 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
 // ------------------------------------------------------------------------------------------------------------
 // Tracker::track for a batch: one workgroup per frame pair, all levels, all LM iterations, keyframe test.
 // ------------------------------------------------------------------------------------------------------------
-template <int BLOCK, bool HUBER, bool DENSE>
+template <int BLOCK, bool HUBER, bool DENSE, bool FUSED>
 // Register budget: with 256-thread workgroups more resident workgroups per CU hide the latency-bound coarse levels of their
 // neighbours (measured at 4096 pairs: dense 5 waves/SIMD = 96 VGPRs +3.7 %, 6 spills; sparse 6 waves/SIMD +4 %).
 #ifndef VORS_LM_WAVES
@@ -745,7 +1047,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const long long t_level0 = wall_clock64();
         const long long c_level0 = clock64();
 #endif
-        with_level_source<DENSE, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
+        with_level_source<DENSE, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
             ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr);
         });
         if (out_stats && threadIdx.x == 0) {
@@ -799,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const int lvl = g.L - 1;
         const Intr k = g.lv[lvl].k;
         if constexpr (DENSE) {
-            with_level_source<true, false>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
+            with_level_source<true, false, false>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
                 for (auto cu = src.template begin<BLOCK>(); cu.i < n_slots; cu = src.template advance<BLOCK>(cu)) {
                     typename std::remove_reference<decltype(src)>::type::Raw r;
                     src.template fetch<BLOCK>(cu, n_slots, r);
@@ -926,7 +1228,7 @@ __device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { retu
 // launch at a higher occupancy) for the pairs at the back of the list; g and H (compute_eval_data, :90-107) follow in a later
 // round only if the candidate is accepted AND the level goes on — like the reference's `eval`, which never builds them for a
 // rejected candidate.
-template <bool HUBER, bool ENERGY>
+template <bool HUBER, bool ENERGY, bool FUSED>
 __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(ENERGY ? VORS_SPLIT_ENERGY_WAVES : VORS_SPLIT_WAVES))) void
 lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
                      const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round) {
@@ -947,7 +1249,7 @@ lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __
         const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
         float acc[NACC];
         float* out = ws.partials + ((size_t)pair * ws.chunks + chunk) * 32;
-        with_level_source<true, true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+        with_level_source<true, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
             const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
             eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, ENERGY>(
                 src, last, c, model, acc, nullptr, first);
@@ -966,6 +1268,8 @@ lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __
         __syncthreads();
     }
 }
+#if !VORS_FUSED
+// (arithmetic-independent: compiled once, in the exact object)
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
 // step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
 // (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
@@ -1092,15 +1396,23 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
     }
 }
 
+void launch_lm_split_step(LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(lm_split_step_kernel, dim3(grid), dim3(64), 0, s, ws, out_stats, round, late, next_late);
+}
+#else
+// host-side launcher of the (arithmetic-independent) step kernel, defined in the exact object
+void launch_lm_split_step(LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s);
+#endif
+
 #define VORS_LM_KARGS g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats
 template <int BLOCK, bool DENSE>
 static void launch_lm_track_block(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                   const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats,
                                   int n_pairs, int mode, LmSplitWs split, hipStream_t s) {
     if (g.huber_delta > 0.f)
-        hipLaunchKernelGGL((lm_track_kernel<BLOCK, true, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, true, DENSE, kFused>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
     else
-        hipLaunchKernelGGL((lm_track_kernel<BLOCK, false, DENSE>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
+        hipLaunchKernelGGL((lm_track_kernel<BLOCK, false, DENSE, kFused>), dim3(n_pairs), dim3(BLOCK), 0, s, VORS_LM_KARGS, mode, split);
 }
 static void launch_lm_track_mode(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                  const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs,
@@ -1118,9 +1430,52 @@ static void launch_lm_track_mode(const Geom& g, Pyramid cur, Pyramid kf, const u
 #undef VORS_LM_ARGS
 }
 
-void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
-                     const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
-                     LmSplitWs split, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------------------
+// One evaluation (eval_energy + compute_eval_data, lm_optimizer.rs:68-107) of ONE level of ONE pair of the handle at an explicit
+// model, in this object's arithmetic: the operator-level view of the tracker's own point sources (inspection / parity tests:
+// EXACT vs FUSED sums). out29 = sum r^2 (or Huber loss), n_inside, g[6], H upper triangle[21].
+// ------------------------------------------------------------------------------------------------------------
+template <bool HUBER, bool DENSE, bool FUSED>
+__global__ __launch_bounds__(256) void lm_eval_level_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                             const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                             const uint16_t* __restrict__ kf_depth, Records rec, int pair, int lvl,
+                                                             const float* __restrict__ model7, float* __restrict__ out29) {
+    __shared__ LmShared s;
+    const Iso model = iso_uniform(iso_load(model7));
+    const ImgCtx c = level_ctx(g, cur0, curu, pair, lvl);
+    float acc[NACC];
+    with_level_source<DENSE, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
+        eval_accumulate<256, HUBER, false>(src, n_units, c, model, acc, nullptr);
+    });
+    block_reduce<256>(acc, s, 0);
+    if (threadIdx.x < NACC) out29[threadIdx.x] = s.sums[0][threadIdx.x];
+}
+#if VORS_FUSED
+#define VORS_LAUNCH_LM_EVAL_LEVEL launch_lm_eval_level_fused
+#else
+#define VORS_LAUNCH_LM_EVAL_LEVEL launch_lm_eval_level_exact
+#endif
+void VORS_LAUNCH_LM_EVAL_LEVEL(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
+                               const float* model7, float* out29, hipStream_t s) {
+    Geom g = g_in;
+    g.wide_loads_ok = (((uintptr_t)kf.level0 | (uintptr_t)kf.upper | (uintptr_t)kf_depth | (uintptr_t)rec.IZ) % 16 == 0) ? 1 : 0;
+#define VORS_EL_ARGS dim3(1), dim3(256), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29
+    const bool dense = g.mode == VORS_CANDIDATES_DENSE, huber = g.huber_delta > 0.f;
+    if (dense && huber) hipLaunchKernelGGL((lm_eval_level_kernel<true, true, kFused>), VORS_EL_ARGS);
+    else if (dense) hipLaunchKernelGGL((lm_eval_level_kernel<false, true, kFused>), VORS_EL_ARGS);
+    else if (huber) hipLaunchKernelGGL((lm_eval_level_kernel<true, false, kFused>), VORS_EL_ARGS);
+    else hipLaunchKernelGGL((lm_eval_level_kernel<false, false, kFused>), VORS_EL_ARGS);
+#undef VORS_EL_ARGS
+}
+
+#if VORS_FUSED
+#define VORS_LAUNCH_LM_TRACK launch_lm_track_fused
+#else
+#define VORS_LAUNCH_LM_TRACK launch_lm_track_exact
+#endif
+void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                          const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
+                          LmSplitWs split, hipStream_t s) {
     Geom g = g_in;
     g.wide_loads_ok = (((uintptr_t)kf.level0 | (uintptr_t)kf.upper | (uintptr_t)kf_depth | (uintptr_t)rec.IZ) % 16 == 0) ? 1 : 0;
 #define VORS_LM_MARGS g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block
@@ -1151,20 +1506,30 @@ void launch_lm_track(const Geom& g_in, Pyramid cur, Pyramid kf, const uint16_t* 
         const int grid_full = late ? grid : ((r & 1) ? minor : grid), grid_energy = (r & 1) ? grid : minor;
 #define VORS_SPLIT_KARGS g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, split, r
         if (g.huber_delta > 0.f) {
-            hipLaunchKernelGGL((lm_split_eval_kernel<true, false>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
-            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<true, true>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            hipLaunchKernelGGL((lm_split_eval_kernel<true, false, kFused>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<true, true, kFused>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
         } else {
-            hipLaunchKernelGGL((lm_split_eval_kernel<false, false>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
-            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<false, true>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            hipLaunchKernelGGL((lm_split_eval_kernel<false, false, kFused>), dim3(grid_full), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
+            if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<false, true, kFused>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
         }
 #undef VORS_SPLIT_KARGS
-        hipLaunchKernelGGL(lm_split_step_kernel, dim3(std::max(1, n_pairs / shrink)), dim3(64), 0, s, split, out_stats, r, late, next_late);
+        launch_lm_split_step(split, out_stats, r, late, next_late, std::max(1, n_pairs / shrink), s);
     }
     // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
     launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
                          split, s);
     launch_lm_track_mode(VORS_LM_MARGS, 2, split, s);
 #undef VORS_LM_MARGS
+}
+
+#if !VORS_FUSED
+void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                     const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
+                     LmSplitWs split, hipStream_t s) {
+    if (g.arith == VORS_ARITH_FUSED && g.mode == VORS_CANDIDATES_DENSE)
+        launch_lm_track_fused(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block, split, s);
+    else
+        launch_lm_track_exact(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block, split, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1261,5 +1626,7 @@ void launch_lm_solve_obs(Intr k, int rows, int cols, const uint8_t* image, int n
         hipLaunchKernelGGL(lm_solve_obs_kernel<false>, dim3(1), dim3(OP_BLOCK), 0, s, src, n, make_ctx(k, rows, cols, image, huber_delta),
                            model7, out);
 }
+
+#endif  // !VORS_FUSED
 
 }  // namespace vors

@@ -26,6 +26,7 @@ MAX_LEVELS = 8
 ROW_MAJOR, COL_MAJOR = 0, 1
 CANDIDATES_COARSE_TO_FINE, CANDIDATES_DENSE, CANDIDATES_DSO = 0, 1, 2
 TRACK_OK, TRACK_OPTIMIZER_FAILED_POSE_KEPT = 0, 1
+ARITH_EXACT, ARITH_FUSED = 0, 1
 
 
 class VorsError(RuntimeError):
@@ -45,6 +46,7 @@ class vors_config(C.Structure):
         ("idepth_variance", C.c_float),
         ("candidates_mode", C.c_int32),
         ("huber_delta", C.c_float),
+        ("arithmetic", C.c_int32),
     ]
 
 
@@ -93,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "vors_batch_create", "vors_batch_track_pairs", "vors_batch_prepare_keyframes", "vors_batch_track_current",
     "vors_batch_workspace_bytes", "vors_batch_enable_kernel_timing", "vors_batch_kernel_times", "vors_batch_last_kernel_ms",
     "vors_batch_destroy",
-    "vors_batch_get_keyframe_image", "vors_batch_get_current_image", "vors_batch_get_points",
+    "vors_batch_get_keyframe_image", "vors_batch_get_current_image", "vors_batch_get_points", "vors_batch_eval_level",
     "vors_lm_eval", "vors_lm_step", "vors_lm_solve",
     "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
     "vors_synth_render_pairs",
@@ -140,6 +142,7 @@ def lib():
         _lib.vors_batch_get_keyframe_image.argtypes = [vp, i, i, vp, C.POINTER(i), C.POINTER(i)]
         _lib.vors_batch_get_current_image.argtypes = [vp, i, i, vp, C.POINTER(i), C.POINTER(i)]
         _lib.vors_batch_get_points.argtypes = [vp, i, i, i, vp, vp, vp, vp, C.POINTER(i)]
+        _lib.vors_batch_eval_level.argtypes = [vp, i, i, vp, i, vp]
         _lib.vors_lm_eval.argtypes = [C.POINTER(vors_obs), vp, C.POINTER(f), C.POINTER(C.c_int32), vp, vp, vp]
         _lib.vors_lm_step.argtypes = [vp, vp, vp, f, vp, C.POINTER(i)]
         _lib.vors_lm_solve.argtypes = [C.POINTER(vors_obs), vp, vp, C.POINTER(C.c_int32), C.POINTER(f), C.POINTER(f), C.POINTER(i)]
@@ -187,7 +190,7 @@ class Config:
     """src/core/track/inverse_compositional.rs:37-49 (+ two extension fields, zero = reference behaviour)."""
 
     def __init__(self, nb_levels=6, candidates_diff_threshold=7, depth_scale=DEPTH_SCALE, intrinsics=INTRINSICS_FR1,
-                 idepth_variance=0.0001, candidates_mode=CANDIDATES_COARSE_TO_FINE, huber_delta=0.0):
+                 idepth_variance=0.0001, candidates_mode=CANDIDATES_COARSE_TO_FINE, huber_delta=0.0, arithmetic=ARITH_EXACT):
         self.nb_levels = nb_levels
         self.candidates_diff_threshold = candidates_diff_threshold
         self.depth_scale = depth_scale
@@ -195,12 +198,13 @@ class Config:
         self.idepth_variance = idepth_variance
         self.candidates_mode = candidates_mode
         self.huber_delta = huber_delta
+        self.arithmetic = arithmetic
 
     def to_c(self):
         k = self.intrinsics
         return vors_config(self.nb_levels, self.candidates_diff_threshold, self.depth_scale, k.principal_point[0],
                            k.principal_point[1], k.focal[0], k.focal[1], k.skew, self.idepth_variance,
-                           self.candidates_mode, self.huber_delta)
+                           self.candidates_mode, self.huber_delta, self.arithmetic)
 
     def init(self, keyframe_depth_timestamp, depth_map, keyframe_img_timestamp, img, layout=ROW_MAJOR):
         """Config::init (inverse_compositional.rs:74-100) -> Tracker."""
@@ -357,6 +361,16 @@ class Batch:
         _check(lib().vors_batch_track_pairs(self._h, n, self._dp(kf_gray), self._dp(kf_depth), self._dp(cur_gray),
                                             self._dp(prev_poses7), self._dp(out_poses7), self._dp(out_status),
                                             self._dp(out_stats), self._stream()))
+
+    def eval_level(self, pair, level, model7, arithmetic):
+        """One evaluation of a level of a pair at `model7` in the given arithmetic -> (sum r^2, n_inside, g[6], H[6,6])."""
+        m = np.ascontiguousarray(model7, np.float32)
+        out = np.zeros(29, np.float32)
+        _check(lib().vors_batch_eval_level(self._h, pair, level, _ptr(m), int(arithmetic), _ptr(out)))
+        H = np.zeros((6, 6), np.float32)
+        H[np.triu_indices(6)] = out[8:29]
+        H = H + np.triu(H, 1).T
+        return float(out[0]), int(out[1]), out[2:8].copy(), H
 
     def keyframe_image(self, pair, level):
         out = np.empty(self.rows * self.cols, np.uint8)
