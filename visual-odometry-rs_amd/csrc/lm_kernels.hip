@@ -36,6 +36,7 @@ namespace vors {
 
 constexpr bool kFused = VORS_FUSED != 0;
 
+
 #define NACC 29
 #define LM_MAX_WAVES 16
 
@@ -134,6 +135,8 @@ struct DenseSrc {
     float depth_scale;
     struct Cursor {
         int i, x, y;
+        __device__ __forceinline__ int& xq() { return x; }
+        __device__ __forceinline__ const int& xq() const { return x; }
     };
     struct Raw {
         int i, x, y;
@@ -208,6 +211,8 @@ struct DenseQuadSrc {
     const float2* lut;  // level 0: depth -> (inverse depth, 1 / inverse depth), exact table
     struct Cursor {
         int i, qx, y;  // i = quad index
+        __device__ __forceinline__ int& xq() { return qx; }
+        __device__ __forceinline__ const int& xq() const { return qx; }
     };
     struct Loaded {  // raw words of one quad, straight from memory (kept in flight one iteration ahead)
         uint32_t cw, w1, w2, w3, w4;  // level 0: centre/up/down rows + left/right bytes; levels >= 1: fine rows (2 x uint2) + unused
@@ -477,145 +482,257 @@ __device__ __forceinline__ JacK make_jack(const Intr& k) {
     j.s_fuv = uniform_f((float)((double)k.skew / ((double)k.fu * (double)k.fv)));
     return j;
 }
-// One candidate, ready for the fused evaluation.
-struct FPt {
-    float bu, bv, bz;  // H (x, y, 1)^T
-    float a, b;        // x - cu, y - cv
-    float iz;          // inverse depth; 0 for a pixel that is not a candidate (keeps every product finite)
-    float tm;          // template grey level
-    float gu, gv;      // integer gradients as floats (zero on the level-0 border), unused by energy-only evaluations
-    bool valid;
-};
-__device__ __forceinline__ Warped fused_warp(const ImgCtx& c, const FusedCtx& f, const FPt& p) {
-    Warped w;
-    const float hz = fmaf(f.m2, p.iz, p.bz), hu = fmaf(f.m0, p.iz, p.bu), hv = fmaf(f.m1, p.iz, p.bv);
-    const float rz = __builtin_amdgcn_rcpf(hz);
-    w.u = hu * rz;
-    w.v = hv * rz;
-    w.uf = floorf(w.u);
-    w.vf = floorf(w.v);
-    // the reference's strict test (lm_optimizer.rs:227-231); NaN / inf coordinates compare false -> outside
-    w.inside = p.valid && (w.uf >= 0.f) && (w.uf < (float)(c.cols - 2)) && (w.vf >= 0.f) && (w.vf < (float)(c.rows - 2));
-    w.off = (__float2int_rz(w.vf) * c.cols + __float2int_rz(w.uf)) & (w.inside ? -1 : 0);
-    return w;
+__device__ __forceinline__ Taps load_taps_at(const ImgCtx& c, int off) {
+    const unsigned o = (unsigned)off;  // >= 0 by construction; 32-bit offset from the uniform image base
+    uint16_t a, b;
+    __builtin_memcpy(&a, c.img + o, 2);  // two adjacent bytes per row: one (possibly unaligned) 16-bit load each
+    __builtin_memcpy(&b, c.img + (o + (unsigned)c.cols), 2);
+    return Taps{a, b};
 }
-// Fused residual + sums of one point. `cnt` is the lane's integer count of inside points (one add-with-carry; replaces sum 1).
-template <bool HUBER, bool ENERGY_ONLY>
-__device__ __forceinline__ void fused_accumulate(const ImgCtx& c, const JacK& k, const FPt& p, const Warped& w, const Taps& t,
-                                                 float acc[NACC], int& cnt) {
-    const float t00 = (float)(t.top & 0xff), t01 = (float)(t.top >> 8), t10 = (float)(t.bot & 0xff), t11 = (float)(t.bot >> 8);
-    const float fa = w.u - w.uf, fb = w.v - w.vf;
-    const float top = fmaf(fa, t01 - t00, t00), bot = fmaf(fa, t11 - t10, t10);
-    const float im = fmaf(fb, bot - top, top);
-    const float r = w.inside ? im - p.tm : 0.f;  // selected, never multiplied: an outside point contributes exactly nothing
-    cnt += w.inside ? 1 : 0;
-    float wgt = 1.0f, wr = r;
+// A unit (G points of one lane: 4 horizontally adjacent pixels, or one) decoded for the fused evaluation. Everything below is
+// written G-WIDE — each step for all G points before the next step — because on gfx950 a wavefront's dependent VALU instructions
+// issue every ~4.6 cycles however many wavefronts are resident (tools/ubench/valu_occ: ILP 1 -> 4.6, ILP 2 -> 2.7, ILP 4 -> 2.5
+// cycles per instruction): the independent points of a unit are what fills the pipe.
+template <int G>
+struct FUnit {
+    float bu[G], bv[G], bz[G];  // H (x, y, 1)^T
+    float a0, b;                // x0 - cu, y - cv (pixel g of the unit sits at x0 + g)
+    float iz[G];                // inverse depth; 0 for a pixel that is not a candidate (keeps every product finite)
+    uint32_t tmw;               // template grey levels, one byte per point
+    float gu[G], gv[G];         // integer gradients as floats (zero on the level-0 border); not set for energy-only evaluations
+    bool valid[G];
+};
+// What stage C (bilinear, residual, Jacobian, sums) needs of a unit whose taps are in flight.
+// (A software-pipelined loop — stage B of unit k before stage C of unit k-1, raw words of unit k+1 requested first — was built and
+// measured: no gain at 2-6 wavefronts per SIMD, so the loop stays simple.)
+template <int G>
+struct FusedStage {
+    float fa[G], fb[G];  // fractional parts of (u, v)
+    bool inside[G];      // candidate && inside the strict window of lm_optimizer.rs:227-231
+    uint32_t top[G], bot[G];  // tap words (t00 | t01 << 8), (t10 | t11 << 8)
+    uint32_t tmw;
+    float a0, b, iz[G], gu[G], gv[G];
+};
+// Stage B: warp (see the header of this section) + inside test + tap requests.
+template <bool ENERGY_ONLY, int G>
+__device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st) {
+    float hz[G], hu[G], hv[G], rz[G], u[G], v[G], uf[G], vf[G];
+    int off[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) hz[g] = fmaf(f.m2, p.iz[g], p.bz[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) hu[g] = fmaf(f.m0, p.iz[g], p.bu[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) hv[g] = fmaf(f.m1, p.iz[g], p.bv[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) rz[g] = __builtin_amdgcn_rcpf(hz[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) u[g] = hu[g] * rz[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = hv[g] * rz[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) uf[g] = floorf(u[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) vf[g] = floorf(v[g]);
+    const float wlim = (float)(c.cols - 2), hlim = (float)(c.rows - 2);
+#pragma unroll
+    for (int g = 0; g < G; ++g)  // the reference's strict test; NaN / inf coordinates compare false -> outside
+        st.inside[g] = p.valid[g] && (uf[g] >= 0.f) && (uf[g] < wlim) && (vf[g] >= 0.f) && (vf[g] < hlim);
+#pragma unroll
+    for (int g = 0; g < G; ++g) off[g] = (__float2int_rz(vf[g]) * c.cols + __float2int_rz(uf[g])) & (st.inside[g] ? -1 : 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const Taps t = load_taps_at(c, off[g]);
+        st.top[g] = t.top;
+        st.bot[g] = t.bot;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) st.fa[g] = u[g] - uf[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) st.fb[g] = v[g] - vf[g];
+    st.tmw = p.tmw;
+    if (!ENERGY_ONLY) {
+        st.a0 = p.a0;
+        st.b = p.b;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            st.iz[g] = p.iz[g];
+            st.gu[g] = p.gu[g];
+            st.gv[g] = p.gv[g];
+        }
+    }
+}
+// Stage C: lerp-form bilinear interpolation, residual, Jacobian, the 29 sums (`cnt` = the lane's integer count of inside points).
+template <bool HUBER, bool ENERGY_ONLY, int G>
+__device__ __forceinline__ void fused_stage_c(const ImgCtx& c, const JacK& k, const FusedStage<G>& st, float acc[NACC], int& cnt) {
+    uint32_t top[G], bot[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        top[g] = st.top[g];
+        bot[g] = st.bot[g];
+    }
+    float t00[G], d0[G], t10[G], d1[G], tp[G], bt[G], im[G], r[G], tm[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t00[g] = (float)(top[g] & 0xff);
+#pragma unroll
+    for (int g = 0; g < G; ++g) t10[g] = (float)(bot[g] & 0xff);
+#pragma unroll
+    for (int g = 0; g < G; ++g) d0[g] = (float)(top[g] >> 8) - t00[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) d1[g] = (float)(bot[g] >> 8) - t10[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) tp[g] = fmaf(st.fa[g], d0[g], t00[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) bt[g] = fmaf(st.fa[g], d1[g], t10[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) tm[g] = (float)((st.tmw >> (8 * g)) & 0xff);
+#pragma unroll
+    for (int g = 0; g < G; ++g) im[g] = fmaf(st.fb[g], bt[g] - tp[g], tp[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) r[g] = st.inside[g] ? im[g] - tm[g] : 0.f;  // selected, never multiplied: outside contributes nothing
+#pragma unroll
+    for (int g = 0; g < G; ++g) cnt += st.inside[g] ? 1 : 0;
+    float wgt[G], wr[G];
     if (HUBER) {  // extension (not in the reference)
-        const float ar = fabsf(r);
-        const bool lin = ar > c.huber;
-        acc[0] += lin ? c.huber * fmaf(2.0f, ar, -c.huber) : r * r;
-        wgt = lin ? c.huber * __builtin_amdgcn_rcpf(ar) : 1.0f;
-        wr = wgt * r;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float ar = fabsf(r[g]);
+            const bool lin = ar > c.huber;
+            acc[0] += lin ? c.huber * fmaf(2.0f, ar, -c.huber) : r[g] * r[g];
+            wgt[g] = lin ? c.huber * __builtin_amdgcn_rcpf(ar) : 1.0f;
+            wr[g] = wgt[g] * r[g];
+        }
     } else {
-        acc[0] = fmaf(r, r, acc[0]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acc[0] = fmaf(r[g], r[g], acc[0]);
+            wgt[g] = 1.0f;
+            wr[g] = r[g];
+        }
     }
     if (ENERGY_ONLY) return;
     // warp_jacobian_at (inverse_compositional.rs:313-341), linear in (gu, gv); an outside point gets gu = gv = 0 -> J = 0
-    const float gu = w.inside ? p.gu : 0.f, gv = w.inside ? p.gv : 0.f;
-    const float b_fv = p.b * k.inv_fv;                              // per row
-    const float cp = fmaf(p.a, k.inv_fu, -(p.b * k.s_fuv));          // c' = c / (fu fv), c = a fv - s b
-    const float q3 = fmaf(-p.b, b_fv, -k.fv);                        // per row
-    const float p3 = fmaf(-p.a, b_fv, -k.s);
-    const float p4 = fmaf(p.a, cp, k.fu), q4 = p.b * cp;
-    const float p5 = fmaf(k.s, cp, -(k.fu * b_fv)), q5 = cp * k.fv;
-    float J[6];
-    J[0] = (gu * k.fu) * p.iz;
-    J[1] = fmaf(gu, k.s, gv * k.fv) * p.iz;
-    J[2] = -(fmaf(gu, p.a, gv * p.b) * p.iz);
-    J[3] = fmaf(gu, p3, gv * q3);
-    J[4] = fmaf(gu, p4, gv * q4);
-    J[5] = fmaf(gu, p5, gv * q5);
+    const float b = st.b;
+    const float b_fv = b * k.inv_fv, bs = b * k.s_fuv, nfb = -(k.fu * b_fv);  // per unit
+    const float q3 = fmaf(-b, b_fv, -k.fv);
+    float gu[G], gv[G], a[G], cp[G], J[6][G];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q], wr, acc[2 + q]);
-    int h = 8;
+    for (int g = 0; g < G; ++g) gu[g] = st.inside[g] ? st.gu[g] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const float jq = HUBER ? wgt * J[q] : J[q];
+    for (int g = 0; g < G; ++g) gv[g] = st.inside[g] ? st.gv[g] : 0.f;
 #pragma unroll
-        for (int s = q; s < 6; ++s) {
-            acc[h] = fmaf(jq, J[s], acc[h]);
-            ++h;
+    for (int g = 0; g < G; ++g) a[g] = st.a0 + (float)g;
+#pragma unroll
+    for (int g = 0; g < G; ++g) cp[g] = fmaf(a[g], k.inv_fu, -bs);  // c' = c / (fu fv), c = a fv - s b
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[0][g] = (gu[g] * k.fu) * st.iz[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[1][g] = fmaf(gu[g], k.s, gv[g] * k.fv) * st.iz[g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[2][g] = -(fmaf(gu[g], a[g], gv[g] * b) * st.iz[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[3][g] = fmaf(gu[g], fmaf(-a[g], b_fv, -k.s), gv[g] * q3);
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[4][g] = fmaf(gu[g], fmaf(a[g], cp[g], k.fu), gv[g] * (b * cp[g]));
+#pragma unroll
+    for (int g = 0; g < G; ++g) J[5][g] = fmaf(gu[g], fmaf(k.s, cp[g], nfb), gv[g] * (cp[g] * k.fv));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {  // 27 independent accumulators per point
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q][g], wr[g], acc[2 + q]);
+        int h = 8;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float jq = HUBER ? wgt[g] * J[q][g] : J[q][g];
+#pragma unroll
+            for (int s = q; s < 6; ++s) {
+                acc[h] = fmaf(jq, J[s][g], acc[h]);
+                ++h;
+            }
         }
     }
 }
 
-// Fused point sources: the exact sources' loads, decoded into FPt.
+// Fused point sources: the exact sources' loads, decoded into FUnit.
 template <bool LEVEL0>
 struct FusedPixSrc : DenseSrc<LEVEL0> {  // one pixel per unit, any width
     using Base = DenseSrc<LEVEL0>;
     static constexpr bool FUSED = true;
     template <bool ENERGY_ONLY>
-    __device__ __forceinline__ void fpoints(const typename Base::Raw& r, const FusedCtx& f, FPt p[1]) const {
+    __device__ __forceinline__ void funit(const typename Base::Raw& r, const FusedCtx& f, FUnit<1>& p) const {
         const float xf = (float)r.x, yf = (float)r.y;
-        p[0].bu = fmaf(f.h00, xf, fmaf(f.h01, yf, f.h02));
-        p[0].bv = fmaf(f.h10, xf, fmaf(f.h11, yf, f.h12));
-        p[0].bz = fmaf(f.h20, xf, fmaf(f.h21, yf, f.h22));
-        p[0].a = xf - this->k.cu;
-        p[0].b = yf - this->k.cv;
-        p[0].valid = r.valid;
-        p[0].iz = r.valid ? r.izv : 0.f;
-        p[0].tm = (float)r.tm;
-        p[0].gu = (float)r.gx;
-        p[0].gv = (float)r.gy;
+        p.bu[0] = fmaf(f.h00, xf, fmaf(f.h01, yf, f.h02));
+        p.bv[0] = fmaf(f.h10, xf, fmaf(f.h11, yf, f.h12));
+        p.bz[0] = fmaf(f.h20, xf, fmaf(f.h21, yf, f.h22));
+        p.a0 = xf - this->k.cu;
+        p.b = yf - this->k.cv;
+        p.valid[0] = r.valid;
+        p.iz[0] = r.valid ? r.izv : 0.f;
+        p.tmw = (uint32_t)r.tm;
+        p.gu[0] = (float)r.gx;
+        p.gv[0] = (float)r.gy;
     }
 };
 template <bool LEVEL0>
 struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjacent pixels per unit
     using Base = DenseQuadSrc<LEVEL0, false>;
     static constexpr bool FUSED = true;
-    using Raw = typename Base::Loaded;  // decoded straight into FPt
+    using Raw = typename Base::Loaded;  // decoded straight into FUnit
     float depth_scale;
     template <int BLOCK>
     __device__ __forceinline__ void fetch(const typename Base::Cursor& c, int, Raw& r) const {
+#if defined(VORS_EXPERIMENT) && VORS_EXPERIMENT >= 13  // ablation: no keyframe loads at all (values derived from the cursor)
+        r.x0 = 4 * c.qx; r.y = c.y;
+        r.cw = 0x40506070u + c.i; r.w1 = r.cw + 3; r.w2 = r.cw + 5; r.w3 = c.i & 0xff; r.w4 = (c.i >> 3) & 0xff;
+        r.d0 = 0x20003000u + c.i; r.d1 = r.d0 + 77; r.d2 = __float_as_int(0.5f); r.d3 = r.d2;
+        if (!LEVEL0) { r.d0 = r.d1 = r.d2; }
+#else
         this->load(c, r);
+#endif
     }
     template <bool ENERGY_ONLY>
-    __device__ __forceinline__ void fpoints(const Raw& l, const FusedCtx& f, FPt p[4]) const {
+    __device__ __forceinline__ void funit(const Raw& l, const FusedCtx& f, FUnit<4>& p) const {
         const float x0f = (float)l.x0, yf = (float)l.y;
         const float bu0 = fmaf(f.h00, x0f, fmaf(f.h01, yf, f.h02));
         const float bv0 = fmaf(f.h10, x0f, fmaf(f.h11, yf, f.h12));
         const float bz0 = fmaf(f.h20, x0f, fmaf(f.h21, yf, f.h22));
-        const float a0 = x0f - this->kf.k.cu, b = yf - this->kf.k.cv;
-        p[0].bu = bu0; p[1].bu = bu0 + f.h00; p[2].bu = bu0 + f.h00_2; p[3].bu = bu0 + f.h00_3;
-        p[0].bv = bv0; p[1].bv = bv0 + f.h10; p[2].bv = bv0 + f.h10_2; p[3].bv = bv0 + f.h10_3;
-        p[0].bz = bz0; p[1].bz = bz0 + f.h20; p[2].bz = bz0 + f.h20_2; p[3].bz = bz0 + f.h20_3;
-        int tm[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tm[j] = (l.cw >> (8 * j)) & 0xff;
-            p[j].tm = (float)tm[j];
-            p[j].a = a0 + (float)j;
-            p[j].b = b;
-        }
+        p.a0 = x0f - this->kf.k.cu;
+        p.b = yf - this->kf.k.cv;
+        p.bu[0] = bu0; p.bu[1] = bu0 + f.h00; p.bu[2] = bu0 + f.h00_2; p.bu[3] = bu0 + f.h00_3;
+        p.bv[0] = bv0; p.bv[1] = bv0 + f.h10; p.bv[2] = bv0 + f.h10_2; p.bv[3] = bv0 + f.h10_3;
+        p.bz[0] = bz0; p.bz[1] = bz0 + f.h20; p.bz[2] = bz0 + f.h20_2; p.bz[3] = bz0 + f.h20_3;
+        p.tmw = l.cw;
         const int rows = this->rows, cols = this->cols;
         if (LEVEL0) {
+            float dzf[4], rd[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t dz = (j < 2 ? (l.d0 >> (16 * j)) : (l.d1 >> (16 * (j - 2)))) & 0xffffu;
-                p[j].valid = dz != 0;
-                // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); 0 for an unknown depth
-                p[j].iz = p[j].valid ? depth_scale * __builtin_amdgcn_rcpf((float)dz) : 0.f;
+                p.valid[j] = dz != 0;
+                dzf[j] = (float)dz;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rd[j] = __builtin_amdgcn_rcpf(dzf[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)  // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); 0 for an unknown depth
+                p.iz[j] = p.valid[j] ? depth_scale * rd[j] : 0.f;
             if (!ENERGY_ONLY) {  // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33): integer, exact
                 const int yin = (l.y > 0 && l.y < rows - 1) ? -1 : 0;
+                int tm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tm[j] = (l.cw >> (8 * j)) & 0xff;
                 const int bb[6] = {(int)l.w3, tm[0], tm[1], tm[2], tm[3], (int)l.w4};
+                int gx[4], gy[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gx[j] = half_trunc(bb[j + 2] - bb[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gy[j] = half_trunc((int)((l.w2 >> (8 * j)) & 0xff) - (int)((l.w1 >> (8 * j)) & 0xff));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int x = l.x0 + j;
                     const int in = yin & ((x > 0 && x < cols - 1) ? -1 : 0);
-                    const int up = (l.w1 >> (8 * j)) & 0xff, dn = (l.w2 >> (8 * j)) & 0xff;
-                    p[j].gu = (float)(half_trunc(bb[j + 2] - bb[j]) & in);
-                    p[j].gv = (float)(half_trunc(dn - up) & in);
+                    p.gu[j] = (float)(gx[j] & in);
+                    p.gv[j] = (float)(gy[j] & in);
                 }
             }
         } else {
@@ -623,37 +740,23 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float z = __int_as_float((int)zz[j]);
-                p[j].valid = !(z != z);
-                p[j].iz = p[j].valid ? z : 0.f;
-                if (!ENERGY_ONLY) {  // 2x2 block gradients of the next finer level (gradient.rs:74-93): integer, exact
+                p.valid[j] = !(z != z);
+                p.iz[j] = p.valid[j] ? z : 0.f;
+            }
+            if (!ENERGY_ONLY) {  // 2x2 block gradients of the next finer level (gradient.rs:74-93): integer, exact
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
                     const uint32_t w0 = j < 2 ? l.w1 : l.w2, w1 = j < 2 ? l.w3 : l.w4;
                     const int sh = (j & 1) * 16;
                     const int a = (w0 >> sh) & 0xff, cc = (w0 >> (sh + 8)) & 0xff;
                     const int b2 = (w1 >> sh) & 0xff, d = (w1 >> (sh + 8)) & 0xff;
-                    p[j].gu = (float)half_trunc(cc + d - a - b2);
-                    p[j].gv = (float)half_trunc(b2 - a + d - cc);
+                    p.gu[j] = (float)half_trunc(cc + d - a - b2);
+                    p.gv[j] = (float)half_trunc(b2 - a + d - cc);
                 }
             }
         }
     }
 };
-
-// The fused per-group body: all points warped, all taps in flight, then the sums.
-template <bool HUBER, bool ENERGY_ONLY, class Src>
-__device__ __forceinline__ void process_group_fused(const Src& src, const typename Src::Raw& raw, const ImgCtx& c, const FusedCtx& f,
-                                                    const JacK& k, float acc[NACC], int& cnt) {
-    constexpr int G = Src::G;
-    FPt p[G];
-    src.template fpoints<ENERGY_ONLY>(raw, f, p);
-    Warped w[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) w[g] = fused_warp(c, f, p[g]);
-    Taps t[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) t[g] = load_taps(c, w[g]);
-#pragma unroll
-    for (int g = 0; g < G; ++g) fused_accumulate<HUBER, ENERGY_ONLY>(c, k, p[g], w[g], t[g], acc, cnt);
-}
 
 // The per-group body shared by both loop shapes: warp all G points, issue all taps, then Jacobians + sums two points at a
 // time (keeps the live Jacobian registers at 12 while the tap loads are in flight).
@@ -720,7 +823,11 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
         for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
             typename Src::Raw raw;
             src.template fetch<BLOCK>(cur, n_units, raw);
-            process_group_fused<HUBER, ENERGY_ONLY>(src, raw, c, f, jk, acc, cnt);
+            FUnit<Src::G> un;
+            src.template funit<ENERGY_ONLY>(raw, f, un);
+            FusedStage<Src::G> st;
+            fused_stage_b<ENERGY_ONLY>(un, c, f, st);
+            fused_stage_c<HUBER, ENERGY_ONLY>(c, jk, st, acc, cnt);
         }
         acc[1] = (float)cnt;
     } else if constexpr (Src::PREFETCH) {
@@ -1222,6 +1329,13 @@ __device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { retu
 #ifndef VORS_SPLIT_ENERGY_WAVES
 #define VORS_SPLIT_ENERGY_WAVES 8
 #endif
+// fused arithmetic: measured best at the same occupancies (3 / 4 wavefronts per SIMD without any spill: 10-20 % slower)
+#ifndef VORS_FSPLIT_WAVES
+#define VORS_FSPLIT_WAVES 5
+#endif
+#ifndef VORS_FSPLIT_ENERGY_WAVES
+#define VORS_FSPLIT_ENERGY_WAVES 8
+#endif
 // ENERGY = false: full evaluation (energy, g, H) of the pairs at the front of the round's list, at their kept model (init of a
 // level, or the g / H of an accepted candidate) or — late rounds — at their candidate. ENERGY = true: a candidate's energy alone
 // (eval_energy, lm_optimizer.rs:68-87: a third fewer instructions per point and a third of the registers, hence its own
@@ -1229,7 +1343,7 @@ __device__ __forceinline__ int split_chunks(const LmSplitWs& ws, int lvl) { retu
 // round only if the candidate is accepted AND the level goes on — like the reference's `eval`, which never builds them for a
 // rejected candidate.
 template <bool HUBER, bool ENERGY, bool FUSED>
-__global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(ENERGY ? VORS_SPLIT_ENERGY_WAVES : VORS_SPLIT_WAVES))) void
+__global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(FUSED ? (ENERGY ? VORS_FSPLIT_ENERGY_WAVES : VORS_FSPLIT_WAVES) : (ENERGY ? VORS_SPLIT_ENERGY_WAVES : VORS_SPLIT_WAVES)))) void
 lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu, const uint8_t* __restrict__ kf0,
                      const uint8_t* __restrict__ kfu, const uint16_t* __restrict__ kf_depth, Records rec, LmSplitWs ws, int round) {
     __shared__ LmShared s;

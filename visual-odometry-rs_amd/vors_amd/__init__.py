@@ -20,7 +20,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvors_hip.so")
+LIB_PATH = os.environ.get("VORS_HIP_LIB") or os.path.join(_HERE, "libvors_hip.so")  # VORS_HIP_LIB: development builds (ablations)
 MAX_LEVELS = 8
 
 ROW_MAJOR, COL_MAJOR = 0, 1
