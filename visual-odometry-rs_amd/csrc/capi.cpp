@@ -160,7 +160,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
-                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used,
+                     b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used, b->rec.S, b->rec.stage, b->rec.region_cnt,
                      b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
     for (void* p : extra)
         if (p) (void)hipFree(p);
@@ -240,12 +240,14 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.V, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
-    } else {
-        if (e == hipSuccess) e = dmalloc(&b->rec.A, slots, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->rec.B, slots, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->rec.C, slots, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->rec.XY, slots, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
+    } else {  // sparse modes: compact 12-byte candidate lists (+ the keyframe kernel's staging grid in coarse-to-fine mode)
+        if (e == hipSuccess) e = dmalloc(&b->rec.S, slots, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
+        if (g.mode == VORS_CANDIDATES_COARSE_TO_FINE) {
+            keyframe_region_geometry(g, &b->rec.kf_r, &b->rec.n_regions);
+            if (e == hipSuccess) e = dmalloc(&b->rec.stage, slots, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&b->rec.region_cnt, np * VORS_MAX_LEVELS * (size_t)b->rec.n_regions, &b->bytes);
+        }
     }
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DSO) {
         const int rr = (rows + 31) / 32, rc = (cols + 31) / 32;
@@ -276,7 +278,6 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
         if (e == hipSuccess) e = dmalloc(&b->pp.iz, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.counts, np * b->pp.chunks_total, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
     }
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE && !(getenv("VORS_LM_SPLIT") && atoi(getenv("VORS_LM_SPLIT")) == 0)) {
         // evaluation rounds on the finest levels (lm_kernels.hip): chunks per pair so that large batches get ~16 workgroups per pair and
@@ -499,7 +500,9 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     const LevelGeom& lg = b->g.lv[level];
     size_t n = (size_t)lg.n_slots;
     HIP_TRY(hipDeviceSynchronize());
-    if (b->g.mode == VORS_CANDIDATES_DSO) {  // generic-mask mode: the level's slots are compacted, the rest is stale
+    const bool dense = b->g.mode == VORS_CANDIDATES_DENSE;
+    if (!b->kf_level0 || !b->kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "no keyframe has been prepared yet");
+    if (!dense) {  // sparse modes: compact lists
         int used = 0;
         HIP_TRY(hipMemcpy(&used, b->rec.n_used + (size_t)pair * VORS_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
         n = (size_t)std::min(std::max(used, 0), lg.n_slots);
@@ -508,10 +511,8 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     std::vector<float2> C(n);
     std::vector<uint32_t> XY(n);
     std::vector<float> IZ(n);
-    HIP_TRY(hipDeviceSynchronize());
-    if (b->g.mode == VORS_CANDIDATES_DENSE) {
-        // dense mode keeps no per-point records: materialise this level with the LM kernel's own arithmetic
-        if (!b->kf_level0 || !b->kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "no keyframe has been prepared yet");
+    {
+        // no mode keeps full records: materialise this level with the exact arithmetic of the reference's precompute
         DevBuf dA, dB, dC, dXY, dIZ;
         HIP_TRY(dA.alloc(n * 16));
         HIP_TRY(dB.alloc(n * 16));
@@ -519,20 +520,14 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
         HIP_TRY(dXY.alloc(n * 4));
         HIP_TRY(dIZ.alloc(n * 4));
         Records out{dA.as<float4>(), dB.as<float4>(), dC.as<float2>(), dXY.as<uint32_t>(), dIZ.as<float>(), nullptr, nullptr, nullptr};
-        launch_dense_materialize(b->g, level, pair, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, out, nullptr);
+        if (dense) launch_dense_materialize(b->g, level, pair, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, out, nullptr);
+        else launch_slim_materialize(b->g, level, pair, b->rec, (int)n, out, nullptr);
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(A.data(), dA.p, n * sizeof(float4), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(B.data(), dB.p, n * sizeof(float4), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(C.data(), dC.p, n * sizeof(float2), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(XY.data(), dXY.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(IZ.data(), dIZ.p, n * sizeof(float), hipMemcpyDeviceToHost));
-    } else {
-        const size_t base = (size_t)pair * b->g.slots_total + lg.slot_off;
-        HIP_TRY(hipMemcpy(A.data(), b->rec.A + base, n * sizeof(float4), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(B.data(), b->rec.B + base, n * sizeof(float4), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(C.data(), b->rec.C + base, n * sizeof(float2), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(XY.data(), b->rec.XY + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(IZ.data(), b->rec.IZ + base, n * sizeof(float), hipMemcpyDeviceToHost));
     }
     int cnt = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -560,8 +555,6 @@ vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const floa
     if (pair < 0 || pair >= b->prepared_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
     if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED) return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
-    if (arithmetic == VORS_ARITH_FUSED && b->g.mode != VORS_CANDIDATES_DENSE)
-        return fail(VORS_ERR_UNSUPPORTED, "fused arithmetic is implemented for the dense candidate mode");
     DevBuf d_model, d_out;
     HIP_TRY(d_model.alloc(7 * sizeof(float)));
     HIP_TRY(d_out.alloc(32 * sizeof(float)));

@@ -492,17 +492,6 @@ __device__ __forceinline__ float generic_idepth(const Geom& g, const PixelPlanes
     if (l == 0) return level0_idepth(g, depth, mask, (size_t)pair * g.S0 + t);
     return pp.iz[(size_t)pair * pp.stride + pp.off[l] + t];
 }
-__device__ __forceinline__ void generic_write_record(const Records& rec, size_t slot, const Intr& k, int x, int y, float iz, int gx, int gy,
-                                                     uint8_t tmpl) {
-    const V3 P = back_project(k, (float)x, (float)y, 1.0f / iz);
-    float J[6];
-    warp_jacobian_at((float)gx, (float)gy, (float)x, (float)y, iz, k, J);
-    rec.A[slot] = make_float4(P.x, P.y, P.z, (float)tmpl);
-    rec.B[slot] = make_float4(J[0], J[1], J[2], J[3]);
-    rec.C[slot] = make_float2(J[4], J[5]);
-    rec.XY[slot] = (uint32_t)x | ((uint32_t)y << 16);
-    rec.IZ[slot] = iz;
-}
 // Chunk c of a pair covers VORS_CHUNK_PX consecutive pixels (raster order) of one level, 16 consecutive pixels per thread: count pass,
 // then a record pass in which every workgroup sums the counts of the chunks before it in its level to get its first slot.
 __device__ __forceinline__ int chunk_level(const PixelPlanes& pp, int L, int c) {
@@ -595,7 +584,7 @@ __global__ __launch_bounds__(256) void generic_compact_kernel(Geom g, const uint
         if (slot < cap) {
             const int t = t0 + k;
             const int y = t / cols, x = t - y * cols;
-            rec.XY[slot0 + slot] = (uint32_t)x | ((uint32_t)y << 16);
+            rec.S[slot0 + slot].xy = (uint32_t)x | ((uint32_t)y << 16);
         }
         ++slot;
     }
@@ -612,11 +601,12 @@ __global__ __launch_bounds__(256) void generic_build_records_kernel(Geom g, cons
     const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
     const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
     for (int slot = w * 256 + threadIdx.x; slot < n; slot += GENERIC_BUILD_WGS * 256) {
-        const uint32_t xy = rec.XY[slot0 + slot];
+        const uint32_t xy = rec.S[slot0 + slot].xy;
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), t = y * cols + x;
         int gx, gy;
         grad_at(g, kf0, kfu, pair, l, x, y, &gx, &gy);
-        generic_write_record(rec, slot0 + slot, g.lv[l].k, x, y, generic_idepth(g, pp, depth, mask, pair, l, t), gx, gy, img[t]);
+        rec.S[slot0 + slot].iz = generic_idepth(g, pp, depth, mask, pair, l, t);
+        rec.S[slot0 + slot].tg = slim_pack_tg(img[t], gx, gy);
     }
 }
 

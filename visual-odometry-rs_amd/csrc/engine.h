@@ -33,7 +33,22 @@ struct Geom {
     LevelGeom lv[VORS_MAX_LEVELS];
 };
 
-// Candidate record planes (structure of arrays, one entry per slot; pair stride = slots_total):
+// Candidate record of the coarse-to-fine and generic-mask (DSO) modes: 12 bytes per point, everything else (the back-projected point,
+// the warp Jacobian) is recomputed by the LM kernel from it — like the reference's Obs (lm_optimizer.rs:43-58) minus the Jacobians and
+// Hessians it precomputes. Per pair and level the records are COMPACT: slots [0, n_used) hold points, nothing else is ever read.
+struct SlimRec {
+    uint32_t xy;  // x | y << 16
+    float iz;     // inverse depth
+    uint32_t tg;  // template grey level | (gx & 0x3ff) << 8 | (gy & 0x3ff) << 18   (integer gradients of the level, |g| <= 255)
+};
+__host__ __device__ inline uint32_t slim_pack_tg(int tmpl, int gx, int gy) {
+    return (uint32_t)tmpl | (((uint32_t)gx & 0x3ffu) << 8) | (((uint32_t)gy & 0x3ffu) << 18);
+}
+__host__ __device__ inline int slim_gx(uint32_t tg) { return ((int)(tg << 14)) >> 22; }
+__host__ __device__ inline int slim_gy(uint32_t tg) { return ((int)(tg << 4)) >> 22; }
+
+// Operator-level record planes (explicit observations, vors_lm_eval / vors_lm_solve; also the inspection output of
+// vors_batch_get_points). Structure of arrays, one entry per slot:
 //   A = (X, Y, Z, tmpl)  back-projected keyframe point (camera.rs:135-140) + template grey level; tmpl < 0 = empty slot
 //   B = (J0, J1, J2, J3) C = (J4, J5)   warp Jacobian (inverse_compositional.rs:313-341)
 //   XY = x | y << 16     pixel coordinates (keyframe test, inspection)
@@ -46,8 +61,13 @@ struct Records {
     float* IZ;
     float* V;  // dense mode only: fused weight ("variance") plane, < 0 = Unknown
     const float2* LUT;  // dense mode only: depth u16 -> (scale / depth, 1 / (scale / depth)), exact
-    int* n_used;  // [pair][VORS_MAX_LEVELS]; generic-mask mode: slots in use per level (compacted, no holes); dense mode: usable points
-                  // per level counted by the keyframe stage (level 0 only when L >= 2); coarse-to-fine mode: NULL
+    int* n_used;  // [pair][VORS_MAX_LEVELS]; sparse modes: slots in use per level (compact, no holes); dense mode: usable points
+                  // per level counted by the keyframe stage (level 0 only when L >= 2)
+    SlimRec* S;         // coarse-to-fine / generic-mask modes: compact candidate lists, pair stride slots_total, level offset slot_off
+    SlimRec* stage;     // coarse-to-fine mode: the keyframe kernel's slot grid (compacted per wavefront region), input of the per-pair compaction
+    int* region_cnt;    // coarse-to-fine mode: [pair][level][region] points per wavefront region
+    int n_regions;      //   regions per level (= wavefronts of the keyframe kernel per pair)
+    int kf_r;           //   roots per wavefront region
 };
 
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
@@ -121,8 +141,11 @@ void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int
 void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
+void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions);  // coarse-to-fine mode: roots per wavefront region, regions per pair
 void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
                          hipStream_t s);
+// Inspection: expand the slim records of one level of one pair into record planes (exact arithmetic).
+void launch_slim_materialize(const Geom& g, int l, int pair, Records rec, int n, Records out, hipStream_t s);
 void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
                               hipStream_t s);
 // `kf` and `kf_depth` are read only in dense mode (points are recomputed from the keyframe image + depth on the fly).

@@ -261,16 +261,17 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
         }
         __syncthreads();
     }
-    // ---- records. Slot layout [level][wavefront region][j]: the KF_R roots of a wavefront own KF_R * cap contiguous slots of
-    // each level; usable points are COMPACTED to the front of that region (fixed order: by root, then tree slot), the tail is
-    // marked empty. Whole wavefronts of the LM kernel then see either (almost) only points or only empty slots.
+    // ---- records (12 bytes each: coordinates, inverse depth, template + integer gradient; SlimRec). The KF_R roots of a wavefront own
+    // KF_R * cap contiguous slots of each level in the STAGING grid; usable points are compacted to the front of that region (fixed
+    // order: by root, then tree slot) and the region's count is published; compact_regions_kernel then packs the regions of a pair.
+    const int region = blockIdx.x * KF_WAVES + wave;
     for (int l = 0; l < L; ++l) {
         const int cap = 1 << (L - 1 - l), off = cap - 1;
         const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
         const int n_here = min(KF_R, max(0, n_roots - root0)) * cap;  // slots of this region that exist
-        const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off + (size_t)root0 * cap;
+        SlimRec* out = rec.stage + (size_t)pair * g.slots_total + g.lv[l].slot_off + (size_t)root0 * cap;
         int filled = 0;  // wavefront-uniform running count of points written
-        for (int base = 0; base < KF_R * cap; base += 64) {
+        for (int base = 0; base < n_here; base += 64) {
             const int t = base + lane;
             const int rl = t / cap, k = t - rl * cap;
             const bool in = t < n_here;
@@ -281,13 +282,56 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             if (valid) {
                 const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
                 const uint32_t gg = gr[rl * NODES + off + k];
-                write_record(rec, slot0 + filled + before, g.lv[l].k, x, y, sd[rl * NODES + off + k], (int)(int16_t)(gg & 0xffffu),
-                             (int)(int16_t)(gg >> 16), img[(size_t)y * g.lv[l].cols + x]);
+                out[filled + before] = SlimRec{p, sd[rl * NODES + off + k],
+                                               slim_pack_tg(img[(size_t)y * g.lv[l].cols + x], (int)(int16_t)(gg & 0xffffu), (int)(int16_t)(gg >> 16))};
             }
             filled += __popcll(m);
         }
-        for (int t = filled + lane; t < n_here; t += 64) write_empty(rec, slot0 + t);
+        if (lane == 0) rec.region_cnt[((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions + region] = filled;
     }
+}
+
+// Per-pair compaction of the staged regions: one workgroup per (level, pair). Exclusive prefix of the region counts in region order
+// (tiles of 256 regions: wave shuffles + LDS), then a cooperative copy — deterministic order (region, then position inside the region),
+// no atomics. Publishes n_used[pair][level].
+__global__ __launch_bounds__(256) void compact_regions_kernel(Geom g, Records rec) {
+    __shared__ int s_cnt[256], s_pre[256], s_wave[4];
+    __shared__ int s_base;
+    const int l = blockIdx.x, pair = blockIdx.y;
+    const int cap_r = rec.kf_r << (g.L - 1 - l);  // slots per region at this level
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int* cnt = rec.region_cnt + ((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions;
+    const size_t lvl0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
+    const SlimRec* src = rec.stage + lvl0;
+    SlimRec* dst = rec.S + lvl0;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int tile = 0; tile < rec.n_regions; tile += 256) {
+        const int r = tile + (int)threadIdx.x;
+        const int mine = r < rec.n_regions ? cnt[r] : 0;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int pre = s_base + incl - mine;
+        for (int w = 0; w < wave; ++w) pre += s_wave[w];
+        s_cnt[threadIdx.x] = mine;
+        s_pre[threadIdx.x] = pre;
+        __syncthreads();
+        const int n_tile = min(256, rec.n_regions - tile);
+        for (int j = threadIdx.x; j < n_tile * cap_r; j += 256) {
+            const int rr = j / cap_r, k = j - rr * cap_r;
+            if (k < s_cnt[rr]) dst[s_pre[rr] + k] = src[(size_t)(tile + rr) * cap_r + k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_base = pre + mine;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l] = s_base;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -516,12 +560,35 @@ __global__ __launch_bounds__(256) void dense_materialize_kernel(Geom g, int l, i
         write_empty(out, t);
     }
 }
+__global__ __launch_bounds__(256) void slim_materialize_kernel(Geom g, int l, int pair, Records rec, int n, Records out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SlimRec r = rec.S[(size_t)pair * g.slots_total + g.lv[l].slot_off + i];
+    write_record(out, i, g.lv[l].k, (int)(r.xy & 0xffffu), (int)(r.xy >> 16), r.iz, slim_gx(r.tg), slim_gy(r.tg), (uint8_t)(r.tg & 0xff));
+}
+void launch_slim_materialize(const Geom& g, int l, int pair, Records rec, int n, Records out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(slim_materialize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, g, l, pair, rec, n, out);
+}
 void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const uint16_t* depth, Records rec, Records out,
                               hipStream_t s) {
     hipLaunchKernelGGL(dense_materialize_kernel, dim3((g.lv[l].n_slots + 255) / 256), dim3(256), 0, s, g, l, pair, kf.level0, kf.upper,
                        depth, rec, out);
 }
 
+// Region geometry of the coarse-to-fine keyframe kernel (read by capi.cpp when it sizes the handle): roots per wavefront, and
+// wavefront regions per pair.
+static int keyframe_roots_per_wave(const Geom& g) {
+    static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
+    int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
+    while (r > 1 && (size_t)KF_WAVES * r * (1 << g.L) * 16 > 64 * 1024) r >>= 1;  // stay inside the 64 KiB a workgroup may ask for
+    return r;
+}
+void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions) {
+    const int r = keyframe_roots_per_wave(g), n_roots = g.root_rows * g.root_cols;
+    *kf_r = r;
+    *n_regions = ((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r)) * KF_WAVES;
+}
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
     const int n_roots = g.root_rows * g.root_cols;
     if (g.mode == VORS_CANDIDATES_DENSE) {
@@ -542,15 +609,15 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         for (int l = next; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {
-        static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
-        int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
-        while (r > 1 && (size_t)KF_WAVES * r * (1 << g.L) * 16 > 64 * 1024) r >>= 1;  // stay inside the 64 KiB a workgroup may ask for
+        const int r = keyframe_roots_per_wave(g);
         dim3 grid((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r), n_pairs);
+        if (rec.kf_r != r || rec.n_regions != (int)grid.x * KF_WAVES) return;  // the handle was sized for another region geometry (capi.cpp)
         const size_t lds = (size_t)KF_WAVES * r * (1 << g.L) * 16;
         if (r == 8) hipLaunchKernelGGL(keyframe_sparse_kernel<8>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else if (r == 2) hipLaunchKernelGGL(keyframe_sparse_kernel<2>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else hipLaunchKernelGGL(keyframe_sparse_kernel<1>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        hipLaunchKernelGGL(compact_regions_kernel, dim3(g.L, n_pairs), dim3(256), 0, s, g, rec);
     }
 }
 

@@ -113,6 +113,55 @@ struct RecSrc {
     __device__ __forceinline__ int slot(const Raw& r, int g, int n) const { return r.i[g] < n ? r.i[g] : -1; }
 };
 
+// ---- point source: compact 12-byte candidate lists (coarse-to-fine and generic-mask modes of the tracker). G = 2 points (i, i + BLOCK).
+// The back-projected point (camera.rs:135-140 applied to (x, y, 1/_z)) and the warp Jacobian (inverse_compositional.rs:313-341) are
+// recomputed per evaluation with exactly the arithmetic of the reference's precompute: bit-identical values for 12 B of traffic per
+// point instead of 40.
+struct SlimSrc {
+    static constexpr bool FUSED = false;
+    static constexpr int G = 2;
+    static constexpr bool PREFETCH = false;
+    static constexpr bool SKIP_EMPTY = false;
+    const SlimRec* S;
+    Intr k;
+    struct Raw {
+        SlimRec r[2];
+        bool valid[2];
+    };
+    struct Cursor {
+        int i;
+    };
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor begin(int first = 0) const {
+        return Cursor{first + (int)threadIdx.x};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ Cursor advance(const Cursor& c) const {
+        return Cursor{c.i + 2 * BLOCK};
+    }
+    template <int BLOCK>
+    __device__ __forceinline__ void fetch(const Cursor& cur, int n, Raw& r) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int i = cur.i + g * BLOCK;
+            r.valid[g] = i < n;
+            r.r[g] = S[(unsigned)(r.valid[g] ? i : 0)];  // (a lane past the end re-reads record 0 and masks it)
+        }
+    }
+    __device__ __forceinline__ void positions(const Raw& r, Pos p[2]) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const V3 P = back_project(k, (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16), 1.0f / r.r[g].iz);
+            p[g] = Pos{P.x, P.y, P.z, r.valid[g] ? (float)(r.r[g].tg & 0xff) : -1.0f};
+        }
+    }
+    __device__ __forceinline__ void jacobian(const Raw& r, int g, float J[6]) const {
+        warp_jacobian_at((float)slim_gx(r.r[g].tg), (float)slim_gy(r.r[g].tg), (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16),
+                         r.r[g].iz, k, J);
+    }
+    __device__ __forceinline__ int slot(const Raw&, int, int) const { return -1; }
+};
+
 // ---- point sources for dense mode: NOTHING is stored per point at level 0. Each evaluation recomputes the point from the
 // keyframe image (template + integer gradient, gradient.rs:15-33 / 74-93), the depth map (level 0: from_depth,
 // inverse_depth.rs:24-29) or the fused inverse-depth plane (levels >= 1), with exactly the arithmetic of the keyframe
@@ -496,7 +545,7 @@ __device__ __forceinline__ Taps load_taps_at(const ImgCtx& c, int off) {
 template <int G>
 struct FUnit {
     float bu[G], bv[G], bz[G];  // H (x, y, 1)^T
-    float a0, b;                // x0 - cu, y - cv (pixel g of the unit sits at x0 + g)
+    float a[G], b[G];           // x - cu, y - cv
     float iz[G];                // inverse depth; 0 for a pixel that is not a candidate (keeps every product finite)
     uint32_t tmw;               // template grey levels, one byte per point
     float gu[G], gv[G];         // integer gradients as floats (zero on the level-0 border); not set for energy-only evaluations
@@ -511,7 +560,7 @@ struct FusedStage {
     bool inside[G];      // candidate && inside the strict window of lm_optimizer.rs:227-231
     uint32_t top[G], bot[G];  // tap words (t00 | t01 << 8), (t10 | t11 << 8)
     uint32_t tmw;
-    float a0, b, iz[G], gu[G], gv[G];
+    float a[G], b[G], iz[G], gu[G], gv[G];
 };
 // Stage B: warp (see the header of this section) + inside test + tap requests.
 template <bool ENERGY_ONLY, int G>
@@ -552,10 +601,10 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
     for (int g = 0; g < G; ++g) st.fb[g] = v[g] - vf[g];
     st.tmw = p.tmw;
     if (!ENERGY_ONLY) {
-        st.a0 = p.a0;
-        st.b = p.b;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            st.a[g] = p.a[g];
+            st.b[g] = p.b[g];
             st.iz[g] = p.iz[g];
             st.gu[g] = p.gu[g];
             st.gv[g] = p.gv[g];
@@ -612,30 +661,28 @@ __device__ __forceinline__ void fused_stage_c(const ImgCtx& c, const JacK& k, co
     }
     if (ENERGY_ONLY) return;
     // warp_jacobian_at (inverse_compositional.rs:313-341), linear in (gu, gv); an outside point gets gu = gv = 0 -> J = 0
-    const float b = st.b;
-    const float b_fv = b * k.inv_fv, bs = b * k.s_fuv, nfb = -(k.fu * b_fv);  // per unit
-    const float q3 = fmaf(-b, b_fv, -k.fv);
-    float gu[G], gv[G], a[G], cp[G], J[6][G];
+    // (the per-row parts — everything that depends on b alone — are common subexpressions of the four pixels of a quad)
+    float gu[G], gv[G], cp[G], b_fv[G], J[6][G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gu[g] = st.inside[g] ? st.gu[g] : 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) gv[g] = st.inside[g] ? st.gv[g] : 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) a[g] = st.a0 + (float)g;
+    for (int g = 0; g < G; ++g) b_fv[g] = st.b[g] * k.inv_fv;
 #pragma unroll
-    for (int g = 0; g < G; ++g) cp[g] = fmaf(a[g], k.inv_fu, -bs);  // c' = c / (fu fv), c = a fv - s b
+    for (int g = 0; g < G; ++g) cp[g] = fmaf(st.a[g], k.inv_fu, -(st.b[g] * k.s_fuv));  // c' = c / (fu fv), c = a fv - s b
 #pragma unroll
     for (int g = 0; g < G; ++g) J[0][g] = (gu[g] * k.fu) * st.iz[g];
 #pragma unroll
     for (int g = 0; g < G; ++g) J[1][g] = fmaf(gu[g], k.s, gv[g] * k.fv) * st.iz[g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[2][g] = -(fmaf(gu[g], a[g], gv[g] * b) * st.iz[g]);
+    for (int g = 0; g < G; ++g) J[2][g] = -(fmaf(gu[g], st.a[g], gv[g] * st.b[g]) * st.iz[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[3][g] = fmaf(gu[g], fmaf(-a[g], b_fv, -k.s), gv[g] * q3);
+    for (int g = 0; g < G; ++g) J[3][g] = fmaf(gu[g], fmaf(-st.a[g], b_fv[g], -k.s), gv[g] * fmaf(-st.b[g], b_fv[g], -k.fv));
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[4][g] = fmaf(gu[g], fmaf(a[g], cp[g], k.fu), gv[g] * (b * cp[g]));
+    for (int g = 0; g < G; ++g) J[4][g] = fmaf(gu[g], fmaf(st.a[g], cp[g], k.fu), gv[g] * (st.b[g] * cp[g]));
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[5][g] = fmaf(gu[g], fmaf(k.s, cp[g], nfb), gv[g] * (cp[g] * k.fv));
+    for (int g = 0; g < G; ++g) J[5][g] = fmaf(gu[g], fmaf(k.s, cp[g], -(k.fu * b_fv[g])), gv[g] * (cp[g] * k.fv));
 #pragma unroll
     for (int g = 0; g < G; ++g) {  // 27 independent accumulators per point
 #pragma unroll
@@ -664,8 +711,8 @@ struct FusedPixSrc : DenseSrc<LEVEL0> {  // one pixel per unit, any width
         p.bu[0] = fmaf(f.h00, xf, fmaf(f.h01, yf, f.h02));
         p.bv[0] = fmaf(f.h10, xf, fmaf(f.h11, yf, f.h12));
         p.bz[0] = fmaf(f.h20, xf, fmaf(f.h21, yf, f.h22));
-        p.a0 = xf - this->k.cu;
-        p.b = yf - this->k.cv;
+        p.a[0] = xf - this->k.cu;
+        p.b[0] = yf - this->k.cv;
         p.valid[0] = r.valid;
         p.iz[0] = r.valid ? r.izv : 0.f;
         p.tmw = (uint32_t)r.tm;
@@ -696,8 +743,12 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
         const float bu0 = fmaf(f.h00, x0f, fmaf(f.h01, yf, f.h02));
         const float bv0 = fmaf(f.h10, x0f, fmaf(f.h11, yf, f.h12));
         const float bz0 = fmaf(f.h20, x0f, fmaf(f.h21, yf, f.h22));
-        p.a0 = x0f - this->kf.k.cu;
-        p.b = yf - this->kf.k.cv;
+        const float a0 = x0f - this->kf.k.cu, b = yf - this->kf.k.cv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p.a[j] = a0 + (float)j;
+            p.b[j] = b;
+        }
         p.bu[0] = bu0; p.bu[1] = bu0 + f.h00; p.bu[2] = bu0 + f.h00_2; p.bu[3] = bu0 + f.h00_3;
         p.bv[0] = bv0; p.bv[1] = bv0 + f.h10; p.bv[2] = bv0 + f.h10_2; p.bv[3] = bv0 + f.h10_3;
         p.bz[0] = bz0; p.bz[1] = bz0 + f.h20; p.bz[2] = bz0 + f.h20_2; p.bz[3] = bz0 + f.h20_3;
@@ -754,6 +805,36 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
                     p.gv[j] = (float)half_trunc(b2 - a + d - cc);
                 }
             }
+        }
+    }
+};
+
+struct FusedSlimSrc : SlimSrc {  // compact 12-byte candidate lists, two points per unit
+    using Base = SlimSrc;
+    static constexpr bool FUSED = true;
+    template <bool ENERGY_ONLY>
+    __device__ __forceinline__ void funit(const Raw& r, const FusedCtx& f, FUnit<2>& p) const {
+        float xf[2], yf[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            xf[g] = (float)(r.r[g].xy & 0xffffu);
+            yf[g] = (float)(r.r[g].xy >> 16);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) p.bu[g] = fmaf(f.h00, xf[g], fmaf(f.h01, yf[g], f.h02));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) p.bv[g] = fmaf(f.h10, xf[g], fmaf(f.h11, yf[g], f.h12));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) p.bz[g] = fmaf(f.h20, xf[g], fmaf(f.h21, yf[g], f.h22));
+        p.tmw = (r.r[0].tg & 0xffu) | ((r.r[1].tg & 0xffu) << 8);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            p.a[g] = xf[g] - this->k.cu;
+            p.b[g] = yf[g] - this->k.cv;
+            p.valid[g] = r.valid[g];
+            p.iz[g] = r.r[g].iz;  // always a known inverse depth: the lists hold candidates only
+            p.gu[g] = (float)slim_gx(r.r[g].tg);
+            p.gv[g] = (float)slim_gy(r.r[g].tg);
         }
     }
 };
@@ -1088,9 +1169,15 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
             f(src, lg.n_slots);
         }
     } else {
-        const size_t rb = (size_t)pair * g.slots_total + lg.slot_off;
-        RecSrc src{rec.A + rb, rec.B + rb, rec.C + rb};
-        f(src, rec.n_used ? __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]) : lg.n_slots);
+        const SlimRec* S = rec.S + (size_t)pair * g.slots_total + lg.slot_off;
+        const int n = __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]);
+        if constexpr (FUSED) {
+            FusedSlimSrc src{{S, lg.k}};
+            f(src, n);
+        } else {
+            SlimSrc src{S, lg.k};
+            f(src, n);
+        }
     }
 }
 
@@ -1223,20 +1310,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                 }
             });
         } else {
-            const size_t rb = (size_t)pair * g.slots_total + g.lv[lvl].slot_off;
-            const float4* A = rec.A + rb;
-            const uint32_t* XY = rec.XY + rb;
-            const int n_slots = rec.n_used ? rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl] : g.lv[lvl].n_slots;
+            const SlimRec* S = rec.S + (size_t)pair * g.slots_total + g.lv[lvl].slot_off;
+            const int n_slots = rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
             for (int i = threadIdx.x; i < n_slots; i += BLOCK) {
-                const float4 a = A[i];
-                if (a.w >= 0.f) {
-                    const uint32_t p = XY[i];
-                    const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
-                    float u, v;
-                    project_uv(k, iso_transform_point(lm_model, V3{a.x, a.y, a.z}), &u, &v);
-                    flow_sum += fabsf(x - u) + fabsf(y - v);
-                    flow_n += 1.0f;
-                }
+                const SlimRec r = S[i];
+                const float x = (float)(r.xy & 0xffffu), y = (float)(r.xy >> 16);
+                float u, v;
+                project_uv(k, iso_transform_point(lm_model, back_project(k, x, y, 1.0f / r.iz)), &u, &v);  // warp: lm_optimizer.rs:213-219
+                flow_sum += fabsf(x - u) + fabsf(y - v);
+                flow_n += 1.0f;
             }
         }
         block_sum2<BLOCK>(flow_sum, flow_n, s);
@@ -1281,12 +1363,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                     }
                 }
             } else {
-                const float4* A = rec.A + (size_t)pair * g.slots_total + lg.slot_off;
-                if (rec.n_used) {
-                    if (threadIdx.x == 0) n = (float)rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
-                } else {
-                    for (int i = threadIdx.x; i < lg.n_slots; i += BLOCK) n += (A[i].w >= 0.f) ? 1.0f : 0.f;
-                }
+                if (threadIdx.x == 0) n = (float)rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
             }
             block_sum2<BLOCK>(n, dummy, s);
             if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = (int)n;
@@ -1640,7 +1717,7 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
 void launch_lm_track(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                      const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block,
                      LmSplitWs split, hipStream_t s) {
-    if (g.arith == VORS_ARITH_FUSED && g.mode == VORS_CANDIDATES_DENSE)
+    if (g.arith == VORS_ARITH_FUSED)
         launch_lm_track_fused(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block, split, s);
     else
         launch_lm_track_exact(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, block, split, s);
