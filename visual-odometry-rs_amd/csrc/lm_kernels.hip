@@ -546,7 +546,7 @@ template <int G>
 struct FUnit {
     float bu[G], bv[G], bz[G];  // H (x, y, 1)^T
     float a[G], b[G];           // x - cu, y - cv
-    float iz[G];                // inverse depth; 0 for a pixel that is not a candidate (keeps every product finite)
+    float iz[G];                // inverse depth; finite for a pixel that is not a candidate (keeps every product finite)
     uint32_t tmw;               // template grey levels, one byte per point
     float gu[G], gv[G];         // integer gradients as floats (zero on the level-0 border); not set for energy-only evaluations
     bool valid[G];
@@ -565,8 +565,11 @@ struct FusedStage {
 // Stage B: warp (see the header of this section) + inside test + tap requests.
 template <bool ENERGY_ONLY, int G>
 __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st) {
-    float hz[G], hu[G], hv[G], rz[G], u[G], v[G], uf[G], vf[G];
-    int off[G];
+    // gfx950 issues v_fma / v_mul / v_add / shifts every ~2.6 cycles but conversions, compares, selects, v_floor and v_fract every ~4.4
+    // and v_rcp every ~8.9 (tools/ubench/valu_ops): floor-to-integer in ONE conversion (v_cvt_flr_i32_f32), the fractional part in one
+    // v_fract, and the window test as two unsigned integer compares instead of four float ones.
+    float hz[G], hu[G], hv[G], rz[G], u[G], v[G];
+    int iu[G], iv[G], off[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) hz[g] = fmaf(f.m2, p.iz[g], p.bz[g]);
 #pragma unroll
@@ -580,15 +583,16 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = hv[g] * rz[g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) uf[g] = floorf(u[g]);
+    for (int g = 0; g < G; ++g) asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu[g]) : "v"(u[g]));  // (int)floor(u), saturating
 #pragma unroll
-    for (int g = 0; g < G; ++g) vf[g] = floorf(v[g]);
-    const float wlim = (float)(c.cols - 2), hlim = (float)(c.rows - 2);
+    for (int g = 0; g < G; ++g) asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv[g]) : "v"(v[g]));
+    const unsigned wlim = (unsigned)(c.cols - 2), hlim = (unsigned)(c.rows - 2);
 #pragma unroll
-    for (int g = 0; g < G; ++g)  // the reference's strict test; NaN / inf coordinates compare false -> outside
-        st.inside[g] = p.valid[g] && (uf[g] >= 0.f) && (uf[g] < wlim) && (vf[g] >= 0.f) && (vf[g] < hlim);
+    for (int g = 0; g < G; ++g)  // the reference's strict window 0 <= floor(u) < w - 2, 0 <= floor(v) < h - 2 (lm_optimizer.rs:227-231);
+                                 // +-inf saturate to an outside integer. (A NaN coordinate would need hu == hz == 0 exactly.)
+        st.inside[g] = p.valid[g] && ((unsigned)iu[g] < wlim) && ((unsigned)iv[g] < hlim);
 #pragma unroll
-    for (int g = 0; g < G; ++g) off[g] = (__float2int_rz(vf[g]) * c.cols + __float2int_rz(uf[g])) & (st.inside[g] ? -1 : 0);
+    for (int g = 0; g < G; ++g) off[g] = (iv[g] * c.cols + iu[g]) & (st.inside[g] ? -1 : 0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const Taps t = load_taps_at(c, off[g]);
@@ -596,9 +600,9 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
         st.bot[g] = t.bot;
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) st.fa[g] = u[g] - uf[g];
+    for (int g = 0; g < G; ++g) st.fa[g] = __builtin_amdgcn_fractf(u[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) st.fb[g] = v[g] - vf[g];
+    for (int g = 0; g < G; ++g) st.fb[g] = __builtin_amdgcn_fractf(v[g]);
     st.tmw = p.tmw;
     if (!ENERGY_ONLY) {
 #pragma unroll
@@ -765,8 +769,9 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
 #pragma unroll
             for (int j = 0; j < 4; ++j) rd[j] = __builtin_amdgcn_rcpf(dzf[j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)  // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); 0 for an unknown depth
-                p.iz[j] = p.valid[j] ? depth_scale * rd[j] : 0.f;
+            for (int j = 0; j < 4; ++j)  // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); an unknown depth (rcp = inf) is
+                                         // clamped to a finite value (v_min is full rate, a select is not); `valid` masks the point
+                p.iz[j] = fminf(depth_scale * rd[j], 1e18f);
             if (!ENERGY_ONLY) {  // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33): integer, exact
                 const int yin = (l.y > 0 && l.y < rows - 1) ? -1 : 0;
                 int tm[4];
@@ -792,7 +797,7 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
             for (int j = 0; j < 4; ++j) {
                 const float z = __int_as_float((int)zz[j]);
                 p.valid[j] = !(z != z);
-                p.iz[j] = p.valid[j] ? z : 0.f;
+                p.iz[j] = fminf(z, 1e18f);  // Unknown (NaN) -> finite; `valid` masks the point
             }
             if (!ENERGY_ONLY) {  // 2x2 block gradients of the next finer level (gradient.rs:74-93): integer, exact
 #pragma unroll
@@ -1188,7 +1193,7 @@ template <int BLOCK, bool HUBER, bool DENSE, bool FUSED>
 // Register budget: with 256-thread workgroups more resident workgroups per CU hide the latency-bound coarse levels of their
 // neighbours (measured at 4096 pairs: dense 5 waves/SIMD = 96 VGPRs +3.7 %, 6 spills; sparse 6 waves/SIMD +4 %).
 #ifndef VORS_LM_WAVES
-#define VORS_LM_WAVES (BLOCK == 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
+#define VORS_LM_WAVES (BLOCK <= 256 ? (DENSE ? 5 : 6) : (BLOCK == 512 ? 2 : 4))
 #endif
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_WAVES))) void lm_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                           const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
@@ -1612,11 +1617,15 @@ static void launch_lm_track_mode(const Geom& g, Pyramid cur, Pyramid kf, const u
     if (g.mode == VORS_CANDIDATES_DENSE) {
         if (block >= 1024) launch_lm_track_block<1024, true>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, true>(VORS_LM_ARGS);
-        else launch_lm_track_block<256, true>(VORS_LM_ARGS);
+        else if (block >= 256) launch_lm_track_block<256, true>(VORS_LM_ARGS);
+        else if (block >= 128) launch_lm_track_block<128, true>(VORS_LM_ARGS);
+        else launch_lm_track_block<64, true>(VORS_LM_ARGS);
     } else {
         if (block >= 1024) launch_lm_track_block<1024, false>(VORS_LM_ARGS);
         else if (block >= 512) launch_lm_track_block<512, false>(VORS_LM_ARGS);
-        else launch_lm_track_block<256, false>(VORS_LM_ARGS);
+        else if (block >= 256) launch_lm_track_block<256, false>(VORS_LM_ARGS);
+        else if (block >= 128) launch_lm_track_block<128, false>(VORS_LM_ARGS);
+        else launch_lm_track_block<64, false>(VORS_LM_ARGS);
     }
 #undef VORS_LM_ARGS
 }
