@@ -81,13 +81,15 @@ typedef struct vors_pair_stats {
     int32_t nb_iter[VORS_MAX_LEVELS];  /* iterations returned by iterative_solve per level (optimizer.rs:57-70); 0 = level not run */
     int32_t n_points[VORS_MAX_LEVELS]; /* usable candidates per level (extract_z, inverse_compositional.rs:260-279) */
     float energy[VORS_MAX_LEVELS];     /* energy of the state kept at each level */
+    int32_t nb_grad_evals[VORS_MAX_LEVELS]; /* of the nb_iter + 1 evaluations of a level, those for which the reference also forms g and H
+                                             * (compute_eval_data, lm_optimizer.rs:90-107,147): the initial one and every accepted candidate */
 } vors_pair_stats;
 
 const char* vors_last_error(void);
 /* Number of visible HIP devices (0 when none / no runtime). Never fails. */
 int vors_device_count(void);
 /* ABI version of this header: bump on any signature change. */
-int vors_abi_version(void);  /* 2: vors_config.arithmetic */
+int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces

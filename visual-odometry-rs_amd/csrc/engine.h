@@ -97,6 +97,7 @@ struct LmSplitState {  // per pair
     float sums[32];    // sums of the kept state (energy sum, n, g[6], H upper triangle[21])
     float cur_energy, lm_coef;
     int nb_iter;
+    int n_full;        // initial evaluation + accepted candidates of this level so far (statistics: vors_pair_stats.nb_grad_evals)
     int lvl;           // level being solved
     int phase;         // 0 init evaluation pending (full), 1 candidate's energy pending, 4 accepted candidate's g and H pending (full),
                        // 2 all levels finished

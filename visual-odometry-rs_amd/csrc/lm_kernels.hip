@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
 // (inverse_compositional.rs:195-199).
 template <int BLOCK, bool HUBER, class Src>
 __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* model, int* nb_iter_out, float* energy_out,
-                            float* lm_coef_out, LmShared& s, const LmSplitState* resume = nullptr) {
+                            float* lm_coef_out, LmShared& s, const LmSplitState* resume = nullptr, int* n_full_out = nullptr) {
     float acc[NACC];
     Iso cur_model = *model;
     int cur = 0;
@@ -1017,6 +1017,7 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
     int nb_iter = 0;
     Iso cand = cur_model;
     bool have_cand = false;
+    int n_full = resume ? __builtin_amdgcn_readfirstlane(resume->n_full) : 1;  // the initial evaluation + every accepted candidate (statistics)
     if (resume) {  // split path: the level was started by the chip-wide launches; a candidate is waiting for its evaluation
         if (threadIdx.x < NACC) s.sums[0][threadIdx.x] = resume->sums[threadIdx.x];
         __syncthreads();
@@ -1054,6 +1055,7 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
             continue;
         }
         const float d_energy = cur_energy - energy;
+        n_full += 1;    // accepted: the reference forms its g and H (lm_optimizer.rs:147)
         cur = 1 - cur;  // the candidate's sums become the kept state (no copy)
         cur_energy = energy;
         cur_model = cand;
@@ -1065,6 +1067,7 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
     *nb_iter_out = nb_iter;
     *energy_out = cur_energy;
     *lm_coef_out = lm_coef;
+    if (n_full_out) *n_full_out = n_full;
     return true;
 }
 
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         c.cols = g.lv[lvl].cols;
         c.k = g.lv[lvl].k;
         c.huber = g.huber_delta;
-        int nb_iter = 0;
+        int nb_iter = 0, n_full = 0;
         float energy = 0.f, lm_coef = 0.f;
         bool ok = false;
 #ifdef VORS_PROFILE_LEVELS
@@ -1247,10 +1250,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const long long c_level0 = clock64();
 #endif
         with_level_source<DENSE, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
-            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr);
+            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr, &n_full);
         });
         if (out_stats && threadIdx.x == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
+            out_stats[pair].nb_grad_evals[lvl] = ok ? n_full : 0;
             out_stats[pair].energy[lvl] = ok ? energy : 0.f;
 #ifdef VORS_PROFILE_LEVELS
             out_stats[pair].energy[lvl] = (float)(wall_clock64() - t_level0) * 0.01f;  // 100 MHz ticks -> microseconds
@@ -1264,6 +1268,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             if (out_stats && threadIdx.x == 0)
                 for (int l2 = lvl - 1; l2 >= 0; --l2) {
                     out_stats[pair].nb_iter[l2] = 0;
+                    out_stats[pair].nb_grad_evals[l2] = 0;
                     out_stats[pair].energy[l2] = 0.f;
                 }
             break;
@@ -1286,6 +1291,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             st->lvl = split.n_split - 1;
             st->phase = 0;
             st->nb_iter = 0;
+            st->n_full = 0;
             st->went_well = went_well ? 1 : 0;
             if (went_well) split_append(split, 0, false, pair);
         }
@@ -1376,6 +1382,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         if (threadIdx.x == 0)
             for (int lvl = g.L; lvl < VORS_MAX_LEVELS; ++lvl) {
                 out_stats[pair].nb_iter[lvl] = 0;
+                out_stats[pair].nb_grad_evals[lvl] = 0;
                 out_stats[pair].n_points[lvl] = 0;
                 out_stats[pair].energy[lvl] = 0.f;
             }
@@ -1501,12 +1508,14 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
             Iso cur_model = iso_load(st->model);
             float lm_coef = st->lm_coef, cur_energy = st->cur_energy;
             int nb_iter = st->nb_iter;
+            int n_full = st->n_full;  // the initial evaluation + every accepted candidate of this level so far (statistics)
             bool take = false, done = false, need_gh = false;
             if (phase == 0) {  // init: lm_optimizer.rs:113-118
                 take = true;
                 cur_energy = energy;
                 lm_coef = 0.1f;
                 nb_iter = 0;
+                n_full = 1;
             } else if (phase == 4) {  // g, H of the candidate accepted one round ago (now the kept model): on to its step()
                 take = true;
             } else {
@@ -1516,6 +1525,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     else lm_coef *= 10.0f;
                 } else {
                     const float d_energy = cur_energy - energy;
+                    n_full += 1;  // accepted: the reference forms its g and H (lm_optimizer.rs:147)
                     cur_energy = energy;
                     cur_model = iso_load(st->cand);
                     if (too_many_iterations) {
@@ -1532,6 +1542,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
             if (done) {  // level finished
                 if (out_stats) {
                     out_stats[pair].nb_iter[lvl] = nb_iter;
+                    out_stats[pair].nb_grad_evals[lvl] = n_full;
                     out_stats[pair].energy[lvl] = cur_energy;
                 }
                 iso_store(cur_model, st->model);
@@ -1540,6 +1551,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     st->lvl = lvl - 1;
                     st->phase = 0;
                     nb_iter = 0;
+                    n_full = 0;
                     again = true;
                 } else {
                     st->phase = 2;
@@ -1580,11 +1592,13 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
                     if (out_stats)
                         for (int l2 = lvl; l2 >= 0; --l2) {
                             out_stats[pair].nb_iter[l2] = 0;
+                            out_stats[pair].nb_grad_evals[l2] = 0;
                             out_stats[pair].energy[l2] = 0.f;
                         }
                 }
             }
             st->nb_iter = nb_iter;
+            st->n_full = n_full;
             // a candidate goes to the energy-only launch of the next round, unless that round is a late one (full evaluations only)
             if (again) split_append(ws, round + 1, st->phase == 1 && !next_late, pair);
         }

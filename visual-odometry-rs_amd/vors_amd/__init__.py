@@ -58,6 +58,7 @@ class vors_pair_stats(C.Structure):
         ("nb_iter", C.c_int32 * MAX_LEVELS),
         ("n_points", C.c_int32 * MAX_LEVELS),
         ("energy", C.c_float * MAX_LEVELS),
+        ("nb_grad_evals", C.c_int32 * MAX_LEVELS),
     ]
 
 
@@ -68,6 +69,7 @@ PAIR_STATS_DTYPE = np.dtype([
     ("nb_iter", np.int32, MAX_LEVELS),
     ("n_points", np.int32, MAX_LEVELS),
     ("energy", np.float32, MAX_LEVELS),
+    ("nb_grad_evals", np.int32, MAX_LEVELS),
 ])
 assert PAIR_STATS_DTYPE.itemsize == C.sizeof(vors_pair_stats)
 
@@ -184,6 +186,15 @@ INTRINSICS_ICL_NUIM = Intrinsics((319.5, 239.5), (481.20, -480.00), 0.0)
 INTRINSICS_FR1 = Intrinsics((318.643040, 255.313989), (517.306408, 516.469215), 0.0)
 INTRINSICS_FR2 = Intrinsics((325.141442, 249.701764), (520.908620, 521.007327), 0.0)
 INTRINSICS_FR3 = Intrinsics((320.106653, 247.632132), (535.433105, 539.212524), 0.0)
+
+
+def scaled_intrinsics(rows, cols, base=INTRINSICS_FR1):
+    """Intrinsics of the synthetic scenes: FR1 for 640x480; other sizes scale by s = cols / 640:
+    f' = s f, c' = s (c + 0.5) - 0.5. Returns (cu, cv, fu, fv, skew)."""
+    s = cols / 640.0
+    cu, cv = base.principal_point
+    fu, fv = base.focal
+    return (s * (cu + 0.5) - 0.5, s * (cv + 0.5) - 0.5, s * fu, s * fv, base.skew)
 
 
 class Config:
