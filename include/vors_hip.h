@@ -136,6 +136,11 @@ typedef struct vors_batch vors_batch;
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
  *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical) */
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
+/* Same on an explicit HIP device (vors_batch_create = the calling thread's current device). The handle remembers its device: every
+ * entry point switches to it for the call and restores the caller's current device; a hip_stream of another device is rejected with
+ * VORS_ERR_INVALID_ARGUMENT. Device buffers passed to the handle must live on that device. */
+vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
+vors_status vors_batch_device(const vors_batch* b, int* device);
 vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
                                    const uint8_t* d_cur_gray, const float* d_prev_poses7 /* nullable */,
                                    float* d_out_poses7, int32_t* d_out_status,
@@ -177,6 +182,30 @@ vors_status vors_batch_get_current_image(vors_batch* b, int pair, int level, uin
  * NOT the reference's column-major order: sort by (x, y) to compare. *n = number of usable candidates. */
 vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capacity, int32_t* xy, float* idepth, float* jac,
                                   uint8_t* tmpl, int* n);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 2b. Several GPUs from ONE process (no torch, no MPI): what a Rust host calls for BASELINE config 4 (4096 pairs over 8 MI355X).
+ *     Frame pairs are independent (a Tracker is self-contained: inverse_compositional.rs:31-34), so pairs shard by contiguous blocks —
+ *     pair i lives on device floor(i / ceil(n / G)) — each device runs its own vors_batch on its own stream with no data-path exchange,
+ *     and the ONLY collective is one all-gather of 8 f32 per pair (pose 7 + status) over RCCL / xGMI (ncclAllGather; 16 KiB per GPU for
+ *     4096 pairs on 8 GPUs), after which every device holds all results. RCCL is loaded at run time (librccl.so) and only when the
+ *     handle spans more than one device.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vors_multi vors_multi;
+/* n_devices <= 0: all visible devices; device_ids NULL: 0 .. n_devices-1. */
+vors_status vors_multi_create(const vors_config* cfg, int n_devices, const int* device_ids, int max_pairs_per_device, int rows, int cols,
+                              vors_multi** out);
+int vors_multi_device_count(const vors_multi* m);
+/* Block of pairs owned by device slot k for a batch of n_pairs_total: [*first, *first + *count). */
+vors_status vors_multi_shard(const vors_multi* m, int n_pairs_total, int k, int* first, int* count);
+/* Device-resident: d_*[k] = device slot k's block (row-major images of ITS pairs, allocated on that device). Runs all devices
+ * concurrently, gathers, and returns poses (n_pairs_total x 7) and statuses on the host. Synchronous. */
+vors_status vors_multi_track_pairs(vors_multi* m, int n_pairs_total, const uint8_t* const* d_kf_gray, const uint16_t* const* d_kf_depth,
+                                   const uint8_t* const* d_cur_gray, float* out_poses7, int32_t* out_status);
+/* Host buffers (row-major, all pairs contiguous): uploads each block to its device first (PCIe-inclusive). */
+vors_status vors_multi_track_pairs_host(vors_multi* m, int n_pairs_total, const uint8_t* kf_gray, const uint16_t* kf_depth,
+                                        const uint8_t* cur_gray, float* out_poses7, int32_t* out_status);
+void vors_multi_destroy(vors_multi* m);
 
 /* One evaluation — eval_energy + compute_eval_data (lm_optimizer.rs:68-107) — of level `level` of pair `pair` as the handle holds it
  * after prepare_keyframes + track_current, at an explicit model (HOST pointer, 7 floats), in the given VORS_ARITH_* mode whatever the

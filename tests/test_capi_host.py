@@ -120,3 +120,12 @@ def test_optimizer_trait_skeleton_on_a_toy_problem():
     obs_target = 3.0
     state, n = Halver.iterative_solve(obs_target, 11.0)
     assert abs(state.x - 3.0) < 2e-3 and 5 < n < 50
+
+
+def test_multi_gpu_entry_fails_loudly_without_gpu():
+    if V.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(V.VorsError, match="no HIP device"):
+        V.MultiGpu(V.Config(nb_levels=3), 4, 32, 32)
+    with pytest.raises(V.VorsError, match="no HIP device"):
+        V.Batch(V.Config(nb_levels=3), 4, 32, 32, device=0)

@@ -23,6 +23,7 @@ static vors_status fail(vors_status st, const std::string& msg) {
     g_last_error = msg;
     return st;
 }
+vors_status vors_set_last_error(vors_status st, const std::string& msg) { return fail(st, msg); }  // for multi.cpp
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
         hipError_t _e = (expr);                                                                                \
@@ -120,6 +121,7 @@ struct vors_batch {
     vors_config cfg;
     Geom g;
     int max_pairs = 0;
+    int device = 0;          // HIP device the workspaces live on (vors_batch_create_on); every entry point switches to it
     int prepared_pairs = 0;  // n_pairs of the last prepare_keyframes: track_current may not ask for more
     uint8_t* kf_upper = nullptr;
     uint8_t* cur_upper = nullptr;
@@ -173,6 +175,21 @@ static void batch_free(vors_batch* b) {
     delete b;
 }
 
+// Entry points run on the handle's device whatever the caller's current device is, and restore the caller's on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+// The stream work is enqueued on must belong to the handle's device (a stream of another device would silently run nothing useful).
+static vors_status check_stream(const vors_batch* b, hipStream_t s);
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() {
@@ -209,6 +226,15 @@ int vors_device_count(void) {
 int vors_abi_version(void) { return 2; }
 
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    return vors_batch_create_on(dev, cfg, max_pairs, rows, cols, out);
+}
+
+vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
     if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (max_pairs < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "max_pairs must be >= 1");
@@ -216,7 +242,11 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     vors_status st = build_geom(cfg, rows, cols, &g);
     if (st != VORS_OK) return st;
     if ((st = require_device()) != VORS_OK) return st;
+    if (device < 0 || device >= vors_device_count()) return fail(VORS_ERR_INVALID_ARGUMENT, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(VORS_ERR_HIP, "hipSetDevice failed");
     vors_batch* b = new vors_batch();
+    b->device = device;
     b->cfg = *cfg;
     b->g = g;
     b->max_pairs = max_pairs;
@@ -333,7 +363,16 @@ vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, i
     return VORS_OK;
 }
 
-void vors_batch_destroy(vors_batch* b) { batch_free(b); }
+void vors_batch_destroy(vors_batch* b) {
+    if (!b) return;
+    DeviceGuard guard(b->device);
+    batch_free(b);
+}
+vors_status vors_batch_device(const vors_batch* b, int* device) {
+    if (!b || !device) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *device = b->device;
+    return VORS_OK;
+}
 
 vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes) {
     if (!b || !bytes) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -362,6 +401,18 @@ vors_status vors_batch_enable_kernel_timing(vors_batch* b, int ring) {
     return VORS_OK;
 }
 
+static vors_status check_stream(const vors_batch* b, hipStream_t s) {
+    if (!s) return VORS_OK;  // the default stream of the handle's device (the guard has switched to it)
+    hipDevice_t d;
+    if (hipStreamGetDevice(s, &d) != hipSuccess) {
+        (void)hipGetLastError();
+        return VORS_OK;  // cannot tell: let the launch report
+    }
+    if ((int)d != b->device)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "the stream belongs to device " + std::to_string((int)d) + " but the handle lives on device " +
+                                                   std::to_string(b->device));
+    return VORS_OK;
+}
 static vors_status check_n(const vors_batch* b, int n_pairs) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
     if (n_pairs < 1 || n_pairs > b->max_pairs) return fail(VORS_ERR_INVALID_ARGUMENT, "n_pairs out of range for this handle");
@@ -374,6 +425,8 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     if (st != VORS_OK) return st;
     if (!d_kf_gray || !d_kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL image pointer");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard guard(b->device);
+    if ((st = check_stream(b, s)) != VORS_OK) return st;
     b->kf_level0 = d_kf_gray;
     b->kf_depth = d_kf_depth;
     b->prepared_pairs = n_pairs;
@@ -435,6 +488,8 @@ vors_status vors_batch_track_current(vors_batch* b, int n_pairs, const uint8_t* 
     vors_status st = check_n(b, n_pairs);
     if (st != VORS_OK) return st;
     if (!d_cur_gray || !d_out_poses7 || !d_out_status) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    DeviceGuard guard(b->device);
+    if ((st = check_stream(b, static_cast<hipStream_t>(hip_stream))) != VORS_OK) return st;
     return batch_track_current(b, n_pairs, d_cur_gray, d_prev_poses7, nullptr, d_out_poses7, d_out_status, d_out_stats,
                                static_cast<hipStream_t>(hip_stream));
 }
@@ -480,6 +535,7 @@ static vors_status get_image(vors_batch* b, const uint8_t* level0, const uint8_t
     if (!b || !out) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     if (!level0) return fail(VORS_ERR_INVALID_ARGUMENT, "no image has been submitted yet");
+    DeviceGuard guard(b->device);
     const LevelGeom& lg = b->g.lv[level];
     const uint8_t* src = level == 0 ? level0 + (size_t)pair * b->g.S0 : upper + (size_t)pair * b->g.upper_stride + lg.img_off;
     HIP_TRY(hipDeviceSynchronize());
@@ -501,6 +557,7 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     if (pair < 0 || pair >= b->max_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     const LevelGeom& lg = b->g.lv[level];
     size_t n = (size_t)lg.n_slots;
+    DeviceGuard guard(b->device);
     HIP_TRY(hipDeviceSynchronize());
     const bool dense = b->g.mode == VORS_CANDIDATES_DENSE;
     if (!b->kf_level0 || !b->kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "no keyframe has been prepared yet");
@@ -557,6 +614,7 @@ vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const floa
     if (pair < 0 || pair >= b->prepared_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
     if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
     if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED) return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
+    DeviceGuard guard(b->device);
     DevBuf d_model, d_out;
     HIP_TRY(d_model.alloc(7 * sizeof(float)));
     HIP_TRY(d_out.alloc(32 * sizeof(float)));
@@ -708,6 +766,7 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
 vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
                                int* track_status) {
     if (!t || !depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(t->batch->device);  // the tracker lives on the device that was current at creation
     hipStream_t s = nullptr;
     const int cur_slot = 1 - t->kf_slot;
     vors_status st = upload_u8(gray, 1, t->rows, t->cols, t->layout, t->gray[cur_slot], t->tmp, s);
@@ -765,7 +824,11 @@ vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stat
     *stats = t->last;
     return VORS_OK;
 }
-void vors_tracker_destroy(vors_tracker* t) { delete t; }
+void vors_tracker_destroy(vors_tracker* t) {
+    if (!t) return;
+    DeviceGuard guard(t->batch ? t->batch->device : 0);  // the buffers are freed on the device they live on
+    delete t;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // operator level

@@ -94,13 +94,15 @@ EXPORTED_SYMBOLS = [
     "vors_tracker_create", "vors_tracker_track", "vors_tracker_current_frame", "vors_tracker_last_stats",
     "vors_tracker_keyframe", "vors_tracker_destroy",
     "vors_track_pairs",
-    "vors_batch_create", "vors_batch_track_pairs", "vors_batch_prepare_keyframes", "vors_batch_track_current",
+    "vors_batch_create", "vors_batch_create_on", "vors_batch_device", "vors_batch_track_pairs", "vors_batch_prepare_keyframes", "vors_batch_track_current",
     "vors_batch_workspace_bytes", "vors_batch_enable_kernel_timing", "vors_batch_kernel_times", "vors_batch_last_kernel_ms",
     "vors_batch_destroy",
     "vors_batch_get_keyframe_image", "vors_batch_get_current_image", "vors_batch_get_points", "vors_batch_eval_level",
     "vors_lm_eval", "vors_lm_step", "vors_lm_solve",
     "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
     "vors_synth_render_pairs",
+    "vors_multi_create", "vors_multi_device_count", "vors_multi_shard", "vors_multi_track_pairs", "vors_multi_track_pairs_host",
+    "vors_multi_destroy",
 ]
 
 _lib = None
@@ -132,6 +134,15 @@ def lib():
         _lib.vors_tracker_destroy.restype = None
         _lib.vors_track_pairs.argtypes = [C.POINTER(vors_config), i, vp, vp, vp, i, i, i, vp, vp, vp, vp]
         _lib.vors_batch_create.argtypes = [C.POINTER(vors_config), i, i, i, C.POINTER(vp)]
+        _lib.vors_batch_create_on.argtypes = [i, C.POINTER(vors_config), i, i, i, C.POINTER(vp)]
+        _lib.vors_batch_device.argtypes = [vp, C.POINTER(i)]
+        _lib.vors_multi_create.argtypes = [C.POINTER(vors_config), i, vp, i, i, i, C.POINTER(vp)]
+        _lib.vors_multi_device_count.argtypes = [vp]
+        _lib.vors_multi_shard.argtypes = [vp, i, i, C.POINTER(i), C.POINTER(i)]
+        _lib.vors_multi_track_pairs.argtypes = [vp, i, vp, vp, vp, vp, vp]
+        _lib.vors_multi_track_pairs_host.argtypes = [vp, i, vp, vp, vp, vp, vp]
+        _lib.vors_multi_destroy.argtypes = [vp]
+        _lib.vors_multi_destroy.restype = None
         _lib.vors_batch_track_pairs.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib.vors_batch_prepare_keyframes.argtypes = [vp, i, vp, vp, vp]
         _lib.vors_batch_track_current.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
@@ -294,15 +305,72 @@ def track_pairs(config, kf_gray, kf_depth, cur_gray, prev_poses7=None, layout=RO
     return poses, status, stats
 
 
+class MultiGpu:
+    """vors_multi_*: ONE process, several devices, pairs sharded by contiguous blocks, one RCCL all-gather of pose + status."""
+
+    def __init__(self, config, max_pairs_per_device, rows, cols, n_devices=0, device_ids=None):
+        self.rows, self.cols = rows, cols
+        self._h = C.c_void_p()
+        cfg = config.to_c()
+        ids = np.ascontiguousarray(device_ids, np.int32) if device_ids is not None else None
+        _check(lib().vors_multi_create(C.byref(cfg), n_devices, _ptr(ids), max_pairs_per_device, rows, cols, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vors_multi_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def device_count(self):
+        return lib().vors_multi_device_count(self._h)
+
+    def shard(self, n_total, k):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().vors_multi_shard(self._h, n_total, k, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def track_pairs_host(self, kf_gray, kf_depth, cur_gray):
+        kf_gray = np.ascontiguousarray(kf_gray, np.uint8)
+        kf_depth = np.ascontiguousarray(kf_depth, np.uint16)
+        cur_gray = np.ascontiguousarray(cur_gray, np.uint8)
+        n = kf_gray.shape[0]
+        if kf_gray.shape[1:] != (self.rows, self.cols):
+            raise VorsError(f"expected [n, {self.rows}, {self.cols}] images, got {kf_gray.shape}")
+        poses = np.zeros((n, 7), np.float32)
+        status = np.zeros(n, np.int32)
+        _check(lib().vors_multi_track_pairs_host(self._h, n, _ptr(kf_gray), _ptr(kf_depth), _ptr(cur_gray), _ptr(poses), _ptr(status)))
+        return poses, status
+
+    def track_pairs(self, shards_kf_gray, shards_kf_depth, shards_cur_gray, n_total):
+        """Device-resident: one torch tensor per device slot (that device's block of pairs)."""
+        nd = self.device_count()
+        arr = lambda ts: (C.c_void_p * nd)(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
+        poses = np.zeros((n_total, 7), np.float32)
+        status = np.zeros(n_total, np.int32)
+        _check(lib().vors_multi_track_pairs(self._h, n_total, arr(shards_kf_gray), arr(shards_kf_depth), arr(shards_cur_gray), _ptr(poses),
+                                            _ptr(status)))
+        return poses, status
+
+
 class Batch:
     """Device-resident engine (vors_batch_*). Tensors are torch CUDA(HIP) tensors; work is enqueued on torch's current
     stream and not synchronised."""
 
-    def __init__(self, config, max_pairs, rows, cols):
+    def __init__(self, config, max_pairs, rows, cols, device=None):
         self.config, self.max_pairs, self.rows, self.cols = config, max_pairs, rows, cols
         self._h = C.c_void_p()
         cfg = config.to_c()
-        _check(lib().vors_batch_create(C.byref(cfg), max_pairs, rows, cols, C.byref(self._h)))
+        if device is None:
+            _check(lib().vors_batch_create(C.byref(cfg), max_pairs, rows, cols, C.byref(self._h)))
+        else:
+            _check(lib().vors_batch_create_on(int(device), C.byref(cfg), max_pairs, rows, cols, C.byref(self._h)))
+
+    def device(self):
+        d = C.c_int()
+        _check(lib().vors_batch_device(self._h, C.byref(d)))
+        return d.value
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
