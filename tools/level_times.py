@@ -4,17 +4,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
 import numpy as np, torch
 import vors_amd as V
-V.LIB_PATH = V.LIB_PATH.replace("libvors_hip.so", os.environ.get("VLIB", "libvors_hip_prof.so"))
-from oracle import oracle as O
+V.LIB_PATH = os.path.join(ROOT, "visual-odometry-rs_amd", "vors_amd", os.environ.get("VLIB", "libvors_hip_prof.so"))
 rows, cols, L = 480, 640, int(os.environ.get("LEVELS", "6"))
-intr = O.scaled_intrinsics(rows, cols)
+intr = V.scaled_intrinsics(rows, cols)
 n = int(os.environ.get("PAIRS", "256"))
 kg, kd, cg, _, gt = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
 poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(n)
 for mode in (0, 1):
-    for blk in (256, 1024):
+    for blk in ((128, 256) if mode == 0 else (64, 256)):
         os.environ["VORS_LM_BLOCK"] = str(blk)
-        b = V.Batch(V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode), n, rows, cols)
+        b = V.Batch(V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=int(os.environ.get('ARITH', '1'))), n, rows, cols)
         b.enable_kernel_timing(4)
         for _ in range(3): b.track_pairs(kg, kd, cg, poses, status, stats)
         torch.cuda.synchronize()
