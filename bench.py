@@ -370,6 +370,28 @@ def main():
                     "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2),
                 }
                 del w2
+            # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
+            # own batch of `pairs` pairs; the GPU overlaps the latency-bound tail of one step — straggler rounds, tree descent — with the
+            # VALU-bound body of the next). `value` above stays the single-stream figure: its stage times and roofline are self-consistent.
+            w3 = Workload(V, args, args.candidates, device, seed0 + args.pairs)
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            both = [main_w, w3]
+
+            def alt(i):
+                with torch.cuda.stream(streams[i & 1]):
+                    both[i & 1].step()
+            for i in range(2 * max(args.warmup, 1)):
+                alt(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                alt(i)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            out["pipelined_two_streams"] = {"value": round(args.pairs * args.steps / dt3, 2), "unit": "frame-pairs/s",
+                                            "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                                            "note": "steps alternate between two batch handles on two streams; not the headline"}
+            del w3
         if args.cpu_pairs != 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args, main_w, value)
     if rank == 0:
