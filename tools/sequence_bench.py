@@ -17,7 +17,7 @@ frames_smooth = [O.synth_frame(31337, step * k, rows, cols, intr, frame_salt=k, 
 frames_blocky = [O.synth_frame((1 << 63) | 31337, step * k, rows, cols, intr, frame_salt=k, n_threads=8) for k in range(n)]
 for mode in (0, 1, 2):
     frames = frames_blocky if mode == 2 else frames_smooth  # the DSO selector needs mostly-flat images with edges
-    cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=mode)
+    cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=mode, arithmetic=int(os.environ.get("ARITH", "1")))
     vt = cfg.init(0.0, frames[0][1], 0.0, frames[0][0])
     vt.track(0.0, frames[1][1], 0.0, frames[1][0])  # warm-up
     vt = cfg.init(0.0, frames[0][1], 0.0, frames[0][0])
