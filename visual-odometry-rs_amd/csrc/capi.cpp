@@ -82,6 +82,11 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
         g->lv[l].rows = r;
         g->lv[l].cols = c;
         g->lv[l].k = k;
+        g->lv[l].inv_fu_d = 1.0 / (double)k.fu;
+        g->lv[l].inv_fv_d = 1.0 / (double)k.fv;
+        g->lv[l].inv_fu = (float)g->lv[l].inv_fu_d;
+        g->lv[l].inv_fv = (float)g->lv[l].inv_fv_d;
+        g->lv[l].s_fuv = (float)((double)k.skew / ((double)k.fu * (double)k.fv));
         if (l == 0) {
             g->lv[l].img_off = -1;
         } else {

@@ -16,6 +16,10 @@ struct LevelGeom {
     int slot_off;       // offset of this level's slots inside the per-pair planes (dense: IZ/V planes hold levels >= 1 only; -1 for level 0)
     Intr k;             // intrinsics of this level (camera.rs:106-123)
     FastDiv fu, fv;     // verified fast exact division by the focal lengths of this level (lie.h)
+    // level constants of the FUSED arithmetic, formed once on the host in f64 (the kernels would otherwise redo these divisions in
+    // every evaluation): 1 / fu, 1 / fv as f64 (for H = K R K^-1), and as f32 1 / fu, 1 / fv, s / (fu fv) (Jacobian)
+    double inv_fu_d, inv_fv_d;
+    float inv_fu, inv_fv, s_fuv;
 };
 
 // Everything a kernel needs to know about the batch layout. Passed by value.

@@ -41,7 +41,7 @@ constexpr bool kFused = VORS_FUSED != 0;
 #define LM_MAX_WAVES 16
 
 struct LmShared {
-    float part[LM_MAX_WAVES * 32];  // per-wavefront partial sums
+    float part[LM_MAX_WAVES * 4 * 32];  // partial sums per 16-lane row of each wavefront
     float sums[2][32];              // ping-pong totals: [cur] = kept state's sums, [1-cur] = candidate's
     float cand[8];                  // candidate model (7) + step-ok flag, broadcast from the solving lane
     float misc[LM_MAX_WAVES * 2];
@@ -381,6 +381,8 @@ struct ImgCtx {
     int rows, cols;
     Intr k;
     float huber;
+    double inv_fu_d, inv_fv_d;    // level constants of the fused arithmetic (engine.h LevelGeom), 0 = form them here
+    float inv_fu, inv_fv, s_fuv;
 };
 
 // warp (lm_optimizer.rs:213-219) + interpolate's inside test (lm_optimizer.rs:227-231): tap address or "outside".
@@ -488,7 +490,8 @@ struct FusedCtx {  // uniform per evaluation, kept in scalar registers
     float m0, m1, m2;                                   // m = K t
     float h00_2, h00_3, h10_2, h10_3, h20_2, h20_3;     // 2x / 3x the first column: pixels x0+2, x0+3 of a quad
 };
-__device__ __forceinline__ FusedCtx make_fused_ctx(const Intr& k, const Iso& m) {
+__device__ __forceinline__ FusedCtx make_fused_ctx(const ImgCtx& c, const Iso& m) {
+    const Intr& k = c.k;
     const double qi = m.q.i, qj = m.q.j, qk = m.q.k, qw = m.q.w;
     // R = I + 2 w [q]x + 2 [q]x^2: the matrix of nalgebra's UnitQuaternion * Vector3 (lie.h quat_rotate), no unit-norm assumption
     const double r00 = 1.0 - 2.0 * (qj * qj + qk * qk), r01 = 2.0 * (qi * qj - qk * qw), r02 = 2.0 * (qi * qk + qj * qw);
@@ -499,8 +502,9 @@ __device__ __forceinline__ FusedCtx make_fused_ctx(const Intr& k, const Iso& m) 
     const double a00 = fu * r00 + sk * r10 + cu * r20, a01 = fu * r01 + sk * r11 + cu * r21, a02 = fu * r02 + sk * r12 + cu * r22;
     const double a10 = fv * r10 + cv * r20, a11 = fv * r11 + cv * r21, a12 = fv * r12 + cv * r22;
     // ... K^-1 (camera.rs:135-140): col0 = A0 / fu, col1 = (A1 - s col0) / fv, col2 = A2 - cu col0 - cv col1
-    const double h00 = a00 / fu, h10 = a10 / fu, h20 = r20 / fu;
-    const double h01 = (a01 - sk * h00) / fv, h11 = (a11 - sk * h10) / fv, h21 = (r21 - sk * h20) / fv;
+    const double ifu = c.inv_fu_d != 0.0 ? c.inv_fu_d : 1.0 / fu, ifv = c.inv_fv_d != 0.0 ? c.inv_fv_d : 1.0 / fv;  // (uniform branch)
+    const double h00 = a00 * ifu, h10 = a10 * ifu, h20 = r20 * ifu;
+    const double h01 = (a01 - sk * h00) * ifv, h11 = (a11 - sk * h10) * ifv, h21 = (r21 - sk * h20) * ifv;
     const double h02 = a02 - cu * h00 - cv * h01, h12 = a12 - cu * h10 - cv * h11, h22 = r22 - cu * h20 - cv * h21;
     const double tx = m.t.x, ty = m.t.y, tz = m.t.z;
     FusedCtx f;
@@ -523,12 +527,17 @@ __device__ __forceinline__ bool model_near_identity(const Iso& m) {
 struct JacK {  // level constants of the Jacobian, uniform
     float fu, fv, s, cu, cv, inv_fu, inv_fv, s_fuv;
 };
-__device__ __forceinline__ JacK make_jack(const Intr& k) {
+__device__ __forceinline__ JacK make_jack(const ImgCtx& c) {
+    const Intr& k = c.k;
     JacK j;
     j.fu = k.fu; j.fv = k.fv; j.s = k.skew; j.cu = k.cu; j.cv = k.cv;
-    j.inv_fu = uniform_f((float)(1.0 / (double)k.fu));
-    j.inv_fv = uniform_f((float)(1.0 / (double)k.fv));
-    j.s_fuv = uniform_f((float)((double)k.skew / ((double)k.fu * (double)k.fv)));
+    if (c.inv_fu_d != 0.0) {  // (uniform) formed on the host for the tracker's levels
+        j.inv_fu = c.inv_fu; j.inv_fv = c.inv_fv; j.s_fuv = c.s_fuv;
+    } else {
+        j.inv_fu = uniform_f((float)(1.0 / (double)k.fu));
+        j.inv_fv = uniform_f((float)(1.0 / (double)k.fv));
+        j.s_fuv = uniform_f((float)((double)k.skew / ((double)k.fu * (double)k.fv)));
+    }
     return j;
 }
 __device__ __forceinline__ Taps load_taps_at(const ImgCtx& c, int off) {
@@ -896,8 +905,8 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
                                                                                nullptr, first);
             return;
         }
-        const FusedCtx f = make_fused_ctx(c.k, model);
-        const JacK jk = make_jack(c.k);
+        const FusedCtx f = make_fused_ctx(c, model);
+        const JacK jk = make_jack(c);
         int cnt = 0;  // inside points seen by this lane
         for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
             typename Src::Raw raw;
@@ -951,22 +960,39 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// Workgroup reduction of the 29 partial sums into s.sums[dst][0..28]. Ends with a barrier.
+// Sum over the 16 lanes of a DPP row; every lane of the row ends up with it. (bound_ctrl + full masks: the compiler folds each
+// v_mov_dpp into its v_add_f32, one instruction per step.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_row(float v) {
+    const int t = __builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add_row<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add_row<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add_row<0x141>(v);  // row_half_mirror
+    v = dpp_add_row<0x140>(v);  // row_mirror
+    return v;
+}
+// Workgroup reduction of the 29 partial sums into s.sums[dst][0..28]: four DPP steps inside each 16-lane row (116 instructions per
+// wavefront), the row sums go to LDS straight from one lane per row, 29 threads add the BLOCK / 16 rows in index order. (The first
+// version went on to lane 63 with row_bcast steps and fetched every total with v_readlane + a select: 437 instructions per wavefront
+// and evaluation — 18 % of the coarse-level kernel.) Deterministic for a given BLOCK. Ends with a barrier.
 template <int BLOCK>
 __device__ __forceinline__ void block_reduce(const float acc[NACC], LmShared& s, int dst) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float mine = 0.f;
+    float r[NACC];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(acc[i])), 63));
-        mine = (lane == i) ? tot : mine;
+    for (int i = 0; i < NACC; ++i) r[i] = row_sum16(acc[i]);
+    if ((threadIdx.x & 15) == 0) {
+        float* p = s.part + (threadIdx.x >> 4) * 32;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) p[i] = r[i];
     }
-    if (lane < NACC) s.part[wave * 32 + lane] = mine;
     __syncthreads();
     if (threadIdx.x < NACC) {
         float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) t += s.part[w * 32 + threadIdx.x];
+#pragma unroll 8
+        for (int w = 0; w < BLOCK / 16; ++w) t += s.part[w * 32 + threadIdx.x];
         s.sums[dst][threadIdx.x] = t;
     }
     __syncthreads();
@@ -1235,6 +1261,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         c.cols = g.lv[lvl].cols;
         c.k = g.lv[lvl].k;
         c.huber = g.huber_delta;
+        c.inv_fu_d = g.lv[lvl].inv_fu_d; c.inv_fv_d = g.lv[lvl].inv_fv_d;
+        c.inv_fu = g.lv[lvl].inv_fu; c.inv_fv = g.lv[lvl].inv_fv; c.s_fuv = g.lv[lvl].s_fuv;
         int nb_iter = 0, n_full = 0;
         float energy = 0.f, lm_coef = 0.f;
         bool ok = false;
@@ -1401,6 +1429,8 @@ __device__ __forceinline__ ImgCtx level_ctx(const Geom& g, const uint8_t* cur0, 
     c.cols = g.lv[lvl].cols;
     c.k = g.lv[lvl].k;
     c.huber = g.huber_delta;
+    c.inv_fu_d = g.lv[lvl].inv_fu_d; c.inv_fv_d = g.lv[lvl].inv_fv_d;
+    c.inv_fu = g.lv[lvl].inv_fu; c.inv_fv = g.lv[lvl].inv_fv; c.s_fuv = g.lv[lvl].s_fuv;
     return c;
 }
 #ifndef VORS_SPLIT_WAVES
@@ -1794,6 +1824,8 @@ static ImgCtx make_ctx(Intr k, int rows, int cols, const uint8_t* image, float h
     c.cols = cols;
     c.k = k;
     c.huber = huber;
+    c.inv_fu_d = c.inv_fv_d = 0.0;  // operator level (exact arithmetic): unused
+    c.inv_fu = c.inv_fv = c.s_fuv = 0.f;
     return c;
 }
 void launch_lm_eval_obs(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta,
