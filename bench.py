@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--cpu-pairs", type=int, default=-1, help="pairs timed on the CPU oracle (-1 = auto, 0 = skip)")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other candidate mode, 256-pair batch)")
     p.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (kernel timing off)")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="process-group backend for N > 1: nccl (= RCCL over xGMI, the measured configuration) or gloo (control-plane test of "
+                        "the N > 1 code path on a box with fewer GPUs than ranks: ranks then share devices round-robin)")
     return p.parse_args()
 
 
@@ -148,7 +151,7 @@ def timed_run(work, steps, warmup, world, packed, gathered):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -234,12 +237,19 @@ def main():
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible (RCCL needs one GPU per rank)")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     import vors_amd as V
 
     seed0 = 0x5EED0000 + rank * args.pairs
@@ -328,7 +338,9 @@ def main():
                            "dso": "DSO-style selection (dso.rs, examples/candidates_dso.rs parameters)"}[args.candidates],
             "huber_delta": args.huber,
             "arithmetic": args.arith,
-            "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of pose+status per step" if world > 1 else "1 GPU",
+            "parallelism": (f"pairs sharded over {world} ranks, one all-gather of pose+status per step "
+                            f"({'RCCL over xGMI, one GPU per rank' if args.backend == 'nccl' else 'gloo TEST backend, ranks share ' + str(n_dev) + ' GPU(s)'})"
+                            if world > 1 else "1 GPU"),
             "launch": "hipGraph replay" if args.graph else "eager",
         },
         "roofline": roofline,

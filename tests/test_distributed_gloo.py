@@ -141,3 +141,24 @@ def test_two_ranks_real_engine_equals_single_process(mode, n_total):
     ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg[:k].cpu().numpy(), kd[:k].cpu().numpy().view(np.uint16),
                         cg[:k].cpu().numpy())
     assert np.abs(want_p[:k] - ref["poses"]).max() < 1e-4 and (want_s[:k] == ref["status"]).all()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """bench.py's N > 1 path (rank-dependent seeds, packing pose + status, the gather, barrier + MAX-over-ranks timing, one JSON line from
+    rank 0) launched exactly as the driver launches it, with the gloo TEST backend so that two ranks can share this box's GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--pairs", "64", "--candidates", "c2f", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["pairs_per_gpu"] == 64 and d["failed_pairs"] == 0
+    assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # whole-job aggregate over both ranks
