@@ -675,39 +675,45 @@ __device__ __forceinline__ void fused_stage_c(const ImgCtx& c, const JacK& k, co
     if (ENERGY_ONLY) return;
     // warp_jacobian_at (inverse_compositional.rs:313-341), linear in (gu, gv); an outside point gets gu = gv = 0 -> J = 0
     // (the per-row parts — everything that depends on b alone — are common subexpressions of the four pixels of a quad)
-    float gu[G], gv[G], cp[G], b_fv[G], J[6][G];
+    // Two points at a time: ILP 2 already fills the pipe (tools/ubench/valu_occ) and 12 live Jacobian entries instead of 24 keep the
+    // full evaluation inside its register budget.
+    constexpr int W = G >= 2 ? 2 : 1;
 #pragma unroll
-    for (int g = 0; g < G; ++g) gu[g] = st.inside[g] ? st.gu[g] : 0.f;
+    for (int h = 0; h < G; h += W) {
+        float gu[W], gv[W], cp[W], b_fv[W], J[6][W];
 #pragma unroll
-    for (int g = 0; g < G; ++g) gv[g] = st.inside[g] ? st.gv[g] : 0.f;
+        for (int g = 0; g < W; ++g) gu[g] = st.inside[h + g] ? st.gu[h + g] : 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) b_fv[g] = st.b[g] * k.inv_fv;
+        for (int g = 0; g < W; ++g) gv[g] = st.inside[h + g] ? st.gv[h + g] : 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) cp[g] = fmaf(st.a[g], k.inv_fu, -(st.b[g] * k.s_fuv));  // c' = c / (fu fv), c = a fv - s b
+        for (int g = 0; g < W; ++g) b_fv[g] = st.b[h + g] * k.inv_fv;
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[0][g] = (gu[g] * k.fu) * st.iz[g];
+        for (int g = 0; g < W; ++g) cp[g] = fmaf(st.a[h + g], k.inv_fu, -(st.b[h + g] * k.s_fuv));  // c' = c / (fu fv), c = a fv - s b
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[1][g] = fmaf(gu[g], k.s, gv[g] * k.fv) * st.iz[g];
+        for (int g = 0; g < W; ++g) J[0][g] = (gu[g] * k.fu) * st.iz[h + g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[2][g] = -(fmaf(gu[g], st.a[g], gv[g] * st.b[g]) * st.iz[g]);
+        for (int g = 0; g < W; ++g) J[1][g] = fmaf(gu[g], k.s, gv[g] * k.fv) * st.iz[h + g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[3][g] = fmaf(gu[g], fmaf(-st.a[g], b_fv[g], -k.s), gv[g] * fmaf(-st.b[g], b_fv[g], -k.fv));
+        for (int g = 0; g < W; ++g) J[2][g] = -(fmaf(gu[g], st.a[h + g], gv[g] * st.b[h + g]) * st.iz[h + g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[4][g] = fmaf(gu[g], fmaf(st.a[g], cp[g], k.fu), gv[g] * (st.b[g] * cp[g]));
+        for (int g = 0; g < W; ++g) J[3][g] = fmaf(gu[g], fmaf(-st.a[h + g], b_fv[g], -k.s), gv[g] * fmaf(-st.b[h + g], b_fv[g], -k.fv));
 #pragma unroll
-    for (int g = 0; g < G; ++g) J[5][g] = fmaf(gu[g], fmaf(k.s, cp[g], -(k.fu * b_fv[g])), gv[g] * (cp[g] * k.fv));
+        for (int g = 0; g < W; ++g) J[4][g] = fmaf(gu[g], fmaf(st.a[h + g], cp[g], k.fu), gv[g] * (st.b[h + g] * cp[g]));
 #pragma unroll
-    for (int g = 0; g < G; ++g) {  // 27 independent accumulators per point
+        for (int g = 0; g < W; ++g) J[5][g] = fmaf(gu[g], fmaf(k.s, cp[g], -(k.fu * b_fv[g])), gv[g] * (cp[g] * k.fv));
 #pragma unroll
-        for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q][g], wr[g], acc[2 + q]);
-        int h = 8;
+        for (int g = 0; g < W; ++g) {  // 27 independent accumulators per point
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float jq = HUBER ? wgt[g] * J[q][g] : J[q][g];
+            for (int q = 0; q < 6; ++q) acc[2 + q] = fmaf(J[q][g], wr[h + g], acc[2 + q]);
+            int hh = 8;
 #pragma unroll
-            for (int s = q; s < 6; ++s) {
-                acc[h] = fmaf(jq, J[s][g], acc[h]);
-                ++h;
+            for (int q = 0; q < 6; ++q) {
+                const float jq = HUBER ? wgt[h + g] * J[q][g] : J[q][g];
+#pragma unroll
+                for (int s2 = q; s2 < 6; ++s2) {
+                    acc[hh] = fmaf(jq, J[s2][g], acc[hh]);
+                    ++hh;
+                }
             }
         }
     }
