@@ -347,6 +347,7 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         return fail(VORS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     if (lut) launch_build_depth_lut(g.depth_scale, lut, nullptr);
+    if (g.mode == VORS_CANDIDATES_DENSE) b->g.fast_idepth = (!getenv("VORS_NO_FASTDIV") && verify_fast_idepth(g.depth_scale, nullptr)) ? 1 : 0;
     // Fast exact division by the focal lengths: proven per divisor by exhaustive enumeration on the device, else disabled.
     // Levels halve the focal lengths exactly (camera.rs:119-120), so the level-0 proof covers every level.
     {

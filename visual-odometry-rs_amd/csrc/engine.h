@@ -33,6 +33,7 @@ struct Geom {
     int upper_stride;   // bytes per pair of levels 1..L-1
     int slots_total;    // record slots per pair (all levels)
     int root_rows, root_cols;  // shape of the coarsest level (= roots of the selection quad-trees)
+    int fast_idepth;    // scale / depth through idepth_of<true> (kernels.hip): proven bit-identical to the division for all 65535 depths
     int wide_loads_ok;  // set per launch: the caller's buffers are 16-byte aligned, so the dense quad source may use wide loads
     LevelGeom lv[VORS_MAX_LEVELS];
 };
@@ -178,6 +179,8 @@ void launch_records_from_obs(Intr k, int rows, int cols, const uint8_t* tmpl, in
                              const float* jac, Records rec, hipStream_t s);
 // Exhaustive device check of div_uniform for divisor d (all 2^23 significands); returns true when it is exact.
 bool verify_fastdiv(float d, float r, hipStream_t s);
+// Exhaustive device check of idepth_of<true>(scale, d) == scale / d for d = 1 .. 65535.
+bool verify_fast_idepth(float scale, hipStream_t s);
 // depth -> (inverse depth, its reciprocal) table, 65536 float2 entries (dense mode, level 0).
 void launch_build_depth_lut(float depth_scale, float2* lut, hipStream_t s);
 void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5], double motion_scale,

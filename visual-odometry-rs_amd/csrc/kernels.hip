@@ -367,6 +367,35 @@ __device__ __forceinline__ void fuse_dso_mean(const float dv_in[4], const float 
         *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2] + dv[3] * vv[3]) / *ov;
     }
 }
+// from_depth (inverse_depth.rs:24-29): scale / depth. FAST: q = scale * rcp(d), one residual correction q' = fma(fma(-q, d, scale),
+// rcp(d), q) — 5 instructions instead of the ~12 of an IEEE division — used only after verify_idepth_kernel has found q' equal to the
+// IEEE quotient for EVERY depth 1 .. 65535 at this handle's scale (Geom::fast_idepth); otherwise the division.
+template <bool FAST>
+__device__ __forceinline__ float idepth_of(float scale, uint32_t dz) {
+    const float d = (float)dz;
+    if (FAST) {
+        const float rc = __builtin_amdgcn_rcpf(d);
+        const float q = scale * rc;
+        return fmaf(fmaf(-q, d, scale), rc, q);
+    }
+    return scale / d;
+}
+__global__ void verify_idepth_kernel(float scale, int* mismatch) {
+    const uint32_t dz = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dz == 0 || dz > 65535u) return;
+    if (idepth_of<true>(scale, dz) != idepth_of<false>(scale, dz)) atomicExch(mismatch, 1);
+}
+bool verify_fast_idepth(float scale, hipStream_t s) {
+    if (!(scale == scale) || !(fabsf(scale) < 1e30f) || !(fabsf(scale) > 1e-20f)) return false;
+    int* flag = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)) != hipSuccess) return false;
+    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+    hipLaunchKernelGGL(verify_idepth_kernel, dim3(256), dim3(256), 0, s, scale, flag);
+    int h = 1;
+    const bool ok = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(flag);
+    return ok && h == 0;
+}
 // Wave-aggregated integer counters: usable points per (pair, level), published for the LM kernel's statistics.
 __device__ __forceinline__ void count_add(int* counter, int n) {
 #pragma unroll
@@ -376,6 +405,7 @@ __device__ __forceinline__ void count_add(int* counter, int n) {
 // level 1 straight from the depth map (from_depth, inverse_depth.rs:24-29, fused with the first halve). Also counts the usable
 // pixels of level 0 (non-zero depth; the odd trailing row / column of level 0 has no level-1 parent and is counted by the
 // threads of the last level-1 row / column) and of level 1.
+template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     const int pair = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,7 +420,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const 
         float dv[4], vv[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+            dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
             vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
             n0 += dz[m] != 0;
         }
@@ -410,6 +440,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const 
 }
 // Same, 4 level-1 pixels per thread when cols(level 0) % 8 == 0 and the depth rows are 16-byte aligned: two 16-byte loads, two
 // 16-byte stores.
+template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     const int pair = blockIdx.y;
     const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -428,7 +459,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
             float dv[4], vv[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+                dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
                 vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
                 n0 += dz[m] != 0;
             }
@@ -452,6 +483,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
 // rows): one thread per level-2 pixel reads its 4x4 depth block (four 8-byte loads), fuses the four level-1 pixels (stored:
 // inverse depth only — the level-1 weights are consumed right here and never written) and then the level-2 pixel. Halves the
 // traffic of the two largest inverse-depth passes.
+template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     // TWO horizontally adjacent level-2 pixels per thread: 16-byte loads of the four depth rows, 16-byte stores of the two level-1 rows
     const int pair = blockIdx.y;
@@ -482,7 +514,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const
                 float dv[4], vv[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    dv[m] = dz[m] != 0 ? g.depth_scale / (float)dz[m] : 0.f;
+                    dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
                     vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
                     n0 += dz[m] != 0;
                 }
@@ -598,12 +630,15 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
             // (slots_total and slot_off are multiples of 4, so the vector stores of the wide kernels are aligned)
             const bool aligned = reinterpret_cast<uintptr_t>(depth) % 16 == 0;
             if (g.L >= 3 && aligned && g.lv[0].rows % 4 == 0 && g.lv[0].cols % 16 == 0) {
-                hipLaunchKernelGGL(dense_idepth_level12_kernel, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                if (g.fast_idepth) hipLaunchKernelGGL(dense_idepth_level12_kernel<true>, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                else hipLaunchKernelGGL(dense_idepth_level12_kernel<false>, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
                 next = 3;
             } else if (aligned && g.lv[0].cols % 8 == 0) {
-                hipLaunchKernelGGL(dense_idepth_level1_wide_kernel, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                if (g.fast_idepth) hipLaunchKernelGGL(dense_idepth_level1_wide_kernel<true>, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                else hipLaunchKernelGGL(dense_idepth_level1_wide_kernel<false>, dim3((g.lv[1].n_slots / 4 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
             } else {
-                hipLaunchKernelGGL(dense_idepth_level1_kernel, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                if (g.fast_idepth) hipLaunchKernelGGL(dense_idepth_level1_kernel<true>, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
+                else hipLaunchKernelGGL(dense_idepth_level1_kernel<false>, dim3((g.lv[1].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
             }
         }
         for (int l = next; l < g.L; ++l)
