@@ -40,4 +40,26 @@ __device__ __forceinline__ void grad_at(const Geom& g, const uint8_t* level0, co
 }
 
 
+// Same gradient + the pixel's own grey level from the same round trip: at l >= 1 the level-l pixel IS the floored mean of the 2x2 block
+// the block gradient reads (multires.rs:21-31), at l == 0 the centre pixel is one more load issued with the four neighbours.
+__device__ __forceinline__ void grad_tmpl_at(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l, int x,
+                                             int y, int* gx, int* gy, int* tm) {
+    if (l == 0) {
+        const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+        const uint8_t* p = level0 + (size_t)pair * g.S0 + (size_t)y * cols + x;
+        const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
+        const int l0 = p[interior ? -1 : 0], r0 = p[interior ? 1 : 0], u0 = p[interior ? -cols : 0], d0 = p[interior ? cols : 0];
+        *tm = p[0];
+        *gx = (r0 - l0) / 2;  // borders: the taps alias the centre pixel -> 0, like gradient.rs:15-33
+        *gy = (d0 - u0) / 2;
+    } else {
+        const int fc = g.lv[l - 1].cols;
+        const uint8_t* p = level_ptr(g, level0, upper, pair, l - 1) + (size_t)(2 * y) * fc + 2 * x;
+        const int a = p[0], c = p[1], b = p[fc], d = p[fc + 1];
+        *gx = (c + d - a - b) / 2;
+        *gy = (b - a + d - c) / 2;
+        *tm = (a + b + c + d) >> 2;
+    }
+}
+
 }  // namespace vors

@@ -134,6 +134,12 @@ __device__ __forceinline__ void write_empty(const Records& rec, size_t slot) {
 #define KF_WAVES 4
 // KF_R roots per wavefront: the early tree steps have only 4 * 2^k (node, child) items per root, so several roots share
 // a wavefront (more lanes busy, more independent loads in flight per wave, 1/KF_R as many waves).
+// The wavefronts of a keyframe workgroup never share LDS (each owns the tree nodes of its own roots), so the steps of the descent
+// only need ordering INSIDE a wavefront: LDS operations of a wavefront execute in order; this keeps the compiler from moving them.
+__device__ __forceinline__ void kf_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 template <int KF_R>
 __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, const uint8_t* __restrict__ kf0,
                                                                          const uint8_t* __restrict__ kfu,
@@ -158,16 +164,16 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
         const int root = root0 + lane;
         if (root < n_roots) {
             const int rx = root % g.root_cols, ry = root / g.root_cols;
-            int gx, gy;
-            grad_at(g, kf0, kfu, pair, L - 1, rx, ry, &gx, &gy);
+            int gx, gy, tm;
+            grad_tmpl_at(g, kf0, kfu, pair, L - 1, rx, ry, &gx, &gy, &tm);
             xy[lane * NODES] = (uint32_t)rx | ((uint32_t)ry << 16);
-            gr[lane * NODES] = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
+            gr[lane * NODES] = slim_pack_tg(tm, gx, gy);  // the record's third word, carried through the descent (no gather later)
         } else {
             xy[lane * NODES] = VORS_INVALID_XY;
             gr[lane * NODES] = 0;
         }
     }
-    __syncthreads();
+    kf_wave_sync();
 
     // ---- top-down selection: level l -> l-1. Items = (root, node k, child c); the 4 children of a node sit in one quad.
     const uint32_t thresh = (uint32_t)g.thresh & 0xffffu;
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             const uint32_t pxy = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
             const bool pvalid = pxy != VORS_INVALID_XY;
             const int cx = 2 * (int)(pxy & 0xffffu) + (c >> 1), cy = 2 * (int)(pxy >> 16) + (c & 1);
-            int gx = 0, gy = 0;
-            if (pvalid) grad_at(g, kf0, kfu, pair, l - 1, cx, cy, &gx, &gy);
+            int gx = 0, gy = 0, tm = 0;
+            if (pvalid) grad_tmpl_at(g, kf0, kfu, pair, l - 1, cx, cy, &gx, &gy, &tm);
             const uint32_t g2 = (uint32_t)(gx * gx + gy * gy) & 0xffffu;  // `as u16` wrap, gradient.rs:39-43
             uint32_t v[4];
 #pragma unroll
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             const int myrank = rk[c];
             if (in) {
                 const uint32_t cxy = (uint32_t)cx | ((uint32_t)cy << 16);
-                const uint32_t cg = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
+                const uint32_t cg = slim_pack_tg(tm, gx, gy);
                 if (myrank == 3) {
                     xy[rl * NODES + offc + 2 * k] = pvalid ? cxy : VORS_INVALID_XY;
                     gr[rl * NODES + offc + 2 * k] = cg;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
                 }
             }
         }
-        __syncthreads();
+        kf_wave_sync();
     }
 
     // ---- level 0: inverse depth from the depth map (inverse_depth.rs:24-29); unknown depth -> not a point
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             }
         }
     }
-    __syncthreads();
+    kf_wave_sync();
     // ---- bottom-up fusion (strategy_dso_mean, inverse_depth.rs:81-98)
     for (int l = 1; l < L; ++l) {
         const int cap = 1 << (L - 1 - l);
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
                 xy[dst] = VORS_INVALID_XY;
             }
         }
-        __syncthreads();
+        kf_wave_sync();
     }
     // ---- records (12 bytes each: coordinates, inverse depth, template + integer gradient; SlimRec). The KF_R roots of a wavefront own
     // KF_R * cap contiguous slots of each level in the STAGING grid; usable points are compacted to the front of that region (fixed
@@ -267,7 +273,6 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     const int region = blockIdx.x * KF_WAVES + wave;
     for (int l = 0; l < L; ++l) {
         const int cap = 1 << (L - 1 - l), off = cap - 1;
-        const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
         const int n_here = min(KF_R, max(0, n_roots - root0)) * cap;  // slots of this region that exist
         SlimRec* out = rec.stage + (size_t)pair * g.slots_total + g.lv[l].slot_off + (size_t)root0 * cap;
         int filled = 0;  // wavefront-uniform running count of points written
@@ -279,12 +284,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             const bool valid = p != VORS_INVALID_XY;
             const unsigned long long m = __ballot(valid);
             const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (valid) {
-                const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
-                const uint32_t gg = gr[rl * NODES + off + k];
-                out[filled + before] = SlimRec{p, sd[rl * NODES + off + k],
-                                               slim_pack_tg(img[(size_t)y * g.lv[l].cols + x], (int)(int16_t)(gg & 0xffffu), (int)(int16_t)(gg >> 16))};
-            }
+            if (valid) out[filled + before] = SlimRec{p, sd[rl * NODES + off + k], gr[rl * NODES + off + k]};
             filled += __popcll(m);
         }
         if (lane == 0) rec.region_cnt[((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions + region] = filled;
