@@ -107,6 +107,12 @@ struct LmSplitState {  // per pair
     int phase;         // 0 init evaluation pending (full), 1 candidate's energy pending, 4 accepted candidate's g and H pending (full),
                        // 2 all levels finished
     int went_well;     // 0: a level failed (the pair skips the remaining levels)
+    // FUSED arithmetic: the evaluation context (H = K R K^-1, K t: lm_kernels.hip FusedCtx, 21 floats) of the model the NEXT round
+    // evaluates at level `lvl` — formed once per pair and round by whoever sets that model (the step kernel, the coarse-level kernel's
+    // hand-over) instead of by every thread of every evaluation workgroup — and whether that model is the near-identity case that
+    // runs in the exact arithmetic.
+    float fctx[21];
+    int fctx_exact;
 };
 #define VORS_SPLIT_MAX_ROUNDS 62
 struct LmSplitWs {

@@ -342,30 +342,23 @@ __global__ __launch_bounds__(256) void compact_regions_kernel(Geom g, Records re
 // Fusion follows inverse_depth.rs:49-66,81-98 with the four children in [a,b,c,d] order.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fuse_dso_mean(const float dv_in[4], const float vv_in[4], float* od, float* ov) {
-    float dv[4], vv[4];
+    // Branch-free: an Unknown child adds +0 to both sums. Every product d * v is > 0 and x + 0 == x exactly, so these ARE the
+    // reference's sequential sums over the known children in [a, b, c, d] order — with ONE division per fused pixel instead of one
+    // per distinct child count met in the wavefront. A single known child is passed through (inverse_depth.rs:59-65 never divides it).
+    float sd = 0.f, sv = 0.f, single = 0.f;
     int n = 0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-        if (vv_in[m] >= 0.f) {
-            dv[n] = dv_in[m];
-            vv[n] = vv_in[m];
-            ++n;
-        }
-    *od = __builtin_nanf("");
-    *ov = -1.0f;
-    if (n == 1) {
-        *od = dv[0];
-        *ov = vv[0];
-    } else if (n == 2) {
-        *ov = vv[0] + vv[1];
-        *od = (dv[0] * vv[0] + dv[1] * vv[1]) / *ov;
-    } else if (n == 3) {
-        *ov = vv[0] + vv[1] + vv[2];
-        *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2]) / *ov;
-    } else if (n == 4) {
-        *ov = vv[0] + vv[1] + vv[2] + vv[3];
-        *od = (dv[0] * vv[0] + dv[1] * vv[1] + dv[2] * vv[2] + dv[3] * vv[3]) / *ov;
+    for (int m = 0; m < 4; ++m) {
+        const bool known = vv_in[m] >= 0.f;
+        const float prod = dv_in[m] * vv_in[m];
+        sd += known ? prod : 0.f;
+        sv += known ? vv_in[m] : 0.f;
+        single = known ? dv_in[m] : single;
+        n += known ? 1 : 0;
     }
+    const float q = sd / sv;
+    *od = n == 0 ? __builtin_nanf("") : (n == 1 ? single : q);
+    *ov = n == 0 ? -1.0f : sv;
 }
 // from_depth (inverse_depth.rs:24-29): scale / depth. FAST: q = scale * rcp(d), one residual correction q' = fma(fma(-q, d, scale),
 // rcp(d), q) — 5 instructions instead of the ~12 of an IEEE division — used only after verify_idepth_kernel has found q' equal to the
@@ -379,6 +372,26 @@ __device__ __forceinline__ float idepth_of(float scale, uint32_t dz) {
         return fmaf(fmaf(-q, d, scale), rc, q);
     }
     return scale / d;
+}
+// Level 0 -> level 1 (every known child weighs `var`): fuse_dso_mean of from_depth(children), without the per-child selects of the
+// generic form — an Unknown child enters as d = 0, w = 0, so its product and its terms of all three sums are +0.
+template <bool FAST>
+__device__ __forceinline__ void fuse_depths(float scale, float var, const uint32_t dz[4], float* od, float* ov, int& n0) {
+    float sd = 0.f, sv = 0.f, s1 = 0.f;
+    int n = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const bool known = dz[m] != 0;
+        const float d = known ? idepth_of<FAST>(scale, dz[m]) : 0.f;
+        sd += d * var;
+        sv += known ? var : 0.f;
+        s1 += d;  // a single known child: d + 0 + 0 + 0 == d
+        n += known ? 1 : 0;
+    }
+    n0 += n;
+    const float q = sd / sv;
+    *od = n == 0 ? __builtin_nanf("") : (n == 1 ? s1 : q);
+    *ov = n == 0 ? -1.0f : sv;
 }
 __global__ void verify_idepth_kernel(float scale, int* mismatch) {
     const uint32_t dz = blockIdx.x * blockDim.x + threadIdx.x;
@@ -416,20 +429,13 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const 
         const int fr = g.lv[0].rows, fc = g.lv[0].cols;
         const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(2 * y) * fc + 2 * x;
         // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1) with i=row, j=col   (multires.rs:80-83)
-        const uint16_t dz[4] = {p[0], p[fc], p[1], p[fc + 1]};
-        float dv[4], vv[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
-            vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
-            n0 += dz[m] != 0;
-        }
+        const uint32_t dz[4] = {p[0], p[fc], p[1], p[fc + 1]};
+        float od, ov;
+        fuse_depths<FAST>(g.depth_scale, g.idepth_variance, dz, &od, &ov, n0);
         const bool last_x = x == cols - 1 && (fc & 1), last_y = y == rows - 1 && (fr & 1);
         if (last_x) n0 += (p[2] != 0) + (p[fc + 2] != 0);
         if (last_y) n0 += (p[2 * fc] != 0) + (p[2 * fc + 1] != 0);
         if (last_x && last_y) n0 += p[2 * fc + 2] != 0;
-        float od, ov;
-        fuse_dso_mean(dv, vv, &od, &ov);
         const size_t slot = (size_t)pair * g.slots_total + g.lv[1].slot_off + t;
         rec.IZ[slot] = od;
         rec.V[slot] = ov;
@@ -456,14 +462,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t dz[4] = {w0[k] & 0xffffu, w1[k] & 0xffffu, w0[k] >> 16, w1[k] >> 16};  // a, b, c, d
-            float dv[4], vv[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
-                vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
-                n0 += dz[m] != 0;
-            }
-            fuse_dso_mean(dv, vv, &od[k], &ov[k]);
+            fuse_depths<FAST>(g.depth_scale, g.idepth_variance, dz, &od[k], &ov[k], n0);
             n1 += ov[k] >= 0.f;
         }
         if (y == rows - 1 && (fr & 1)) {  // odd trailing row of level 0 (no odd column: fc % 8 == 0)
@@ -511,14 +510,7 @@ __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const
                 // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1)   (multires.rs:80-83)
                 const uint32_t top = w[2 * i][j], bot = w[2 * i + 1][j];
                 const uint32_t dz[4] = {top & 0xffffu, bot & 0xffffu, top >> 16, bot >> 16};
-                float dv[4], vv[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    dv[m] = dz[m] != 0 ? idepth_of<FAST>(g.depth_scale, dz[m]) : 0.f;
-                    vv[m] = dz[m] != 0 ? g.idepth_variance : -1.0f;
-                    n0 += dz[m] != 0;
-                }
-                fuse_dso_mean(dv, vv, &od1[i][j], &ov1[i][j]);
+                fuse_depths<FAST>(g.depth_scale, g.idepth_variance, dz, &od1[i][j], &ov1[i][j], n0);
                 n1 += ov1[i][j] >= 0.f;
             }
         const size_t s1 = (size_t)pair * g.slots_total + g.lv[1].slot_off + (size_t)(2 * y2) * c1 + 2 * x2;

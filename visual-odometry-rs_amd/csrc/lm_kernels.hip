@@ -524,6 +524,41 @@ __device__ __forceinline__ bool model_near_identity(const Iso& m) {
     const float r = fmaxf(fmaxf(fabsf(m.q.i), fabsf(m.q.j)), fabsf(m.q.k)), t = fmaxf(fmaxf(fabsf(m.t.x), fabsf(m.t.y)), fabsf(m.t.z));
     return __builtin_amdgcn_readfirstlane((r <= 5e-6f && t <= 1e-6f) ? 1 : 0) != 0;
 }
+// The context of (level intrinsics, model) written to / read from the split state (LmSplitState::fctx): formed by ONE thread per
+// pair and round; the evaluation workgroups read it with scalar loads.
+__device__ __forceinline__ void store_fused_ctx(const Geom& g, int lvl, const Iso& model, LmSplitState* st) {
+    ImgCtx c;
+    c.img = nullptr;
+    c.rows = g.lv[lvl].rows;
+    c.cols = g.lv[lvl].cols;
+    c.k = g.lv[lvl].k;
+    c.huber = g.huber_delta;
+    c.inv_fu_d = g.lv[lvl].inv_fu_d; c.inv_fv_d = g.lv[lvl].inv_fv_d;
+    c.inv_fu = g.lv[lvl].inv_fu; c.inv_fv = g.lv[lvl].inv_fv; c.s_fuv = g.lv[lvl].s_fuv;
+    const FusedCtx f = make_fused_ctx(c, model);
+    const float v[21] = {f.h00, f.h01, f.h02, f.h10, f.h11, f.h12, f.h20, f.h21, f.h22, f.m0, f.m1, f.m2,
+                         f.h00_2, f.h00_3, f.h10_2, f.h10_3, f.h20_2, f.h20_3, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 18; ++q) st->fctx[q] = v[q];
+    st->fctx_exact = model_near_identity(model) ? 1 : 0;
+}
+__device__ __forceinline__ FusedCtx load_fused_ctx(const LmSplitState* st) {
+    FusedCtx f;
+    float v[18];
+    // written by an earlier launch, never by this one: read through the constant address space so that the (uniform) loads are scalar
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* cp = (cfloat*)(st->fctx);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) v[q] = cp[q];
+    f.h00 = v[0]; f.h01 = v[1]; f.h02 = v[2]; f.h10 = v[3]; f.h11 = v[4]; f.h12 = v[5]; f.h20 = v[6]; f.h21 = v[7]; f.h22 = v[8];
+    f.m0 = v[9]; f.m1 = v[10]; f.m2 = v[11];
+    f.h00_2 = v[12]; f.h00_3 = v[13]; f.h10_2 = v[14]; f.h10_3 = v[15]; f.h20_2 = v[16]; f.h20_3 = v[17];
+    return f;
+}
+__device__ __forceinline__ bool fused_ctx_exact(const LmSplitState* st) {
+    typedef const int __attribute__((address_space(4))) cint;
+    return *(cint*)(&st->fctx_exact) != 0;
+}
 struct JacK {  // level constants of the Jacobian, uniform
     float fu, fv, s, cu, cv, inv_fu, inv_fv, s_fuv;
 };
@@ -561,16 +596,33 @@ struct FUnit {
     bool valid[G];
 };
 // What stage C (bilinear, residual, Jacobian, sums) needs of a unit whose taps are in flight.
-// (A software-pipelined loop — stage B of unit k before stage C of unit k-1, raw words of unit k+1 requested first — was built and
-// measured: no gain at 2-6 wavefronts per SIMD, so the loop stays simple.)
+// What bounds this loop (round 2, per-kernel probes with tools/lm_variants.sh at 4096 pairs, level-0 rounds):
+//  * not latency: a software-pipelined loop (stage B of unit k+1 and the raw words of unit k+2 requested before stage C of unit k waits
+//    for its taps, two units per basic block) left the energy-only round at 1760-1800 us (1759 as is) and the full round at 3303 (3339);
+//  * the tap gathers, in the energy-only round: every tap load issued twice -> +66 % (full round +24 %), 16 extra FMAs per point -> +1 %
+//    (full +5 %). A 16-bit (or 8-bit, or unaligned 32-bit) gather costs the CU ~19 cycles per wavefront instruction however well the
+//    lanes' addresses line up, an aligned dword 12.7, 8 unaligned bytes 33;
+//  * and VALU issue right behind: the current-image band of a workgroup staged in LDS (sampled bounding rows, 16-byte copies, taps as
+//    ds_read2_b32 + v_alignbyte; every tap served from LDS in the bench) was SLOWER — 1927 / 3359 us: +60 VALU instructions per quad for
+//    the LDS addressing, 4 instead of 8 workgroups per CU, and two barriers plus two memory latencies before a 19-iteration sweep.
+// So the loop stays as simple as it is.
 template <int G>
 struct FusedStage {
     float fa[G], fb[G];  // fractional parts of (u, v)
     bool inside[G];      // candidate && inside the strict window of lm_optimizer.rs:227-231
-    uint32_t top[G], bot[G];  // tap words (t00 | t01 << 8), (t10 | t11 << 8)
+    uint16_t top[G], bot[G];  // tap words (t00 | t01 << 8), (t10 | t11 << 8), as loaded: 16 bits (widened where they are consumed)
     uint32_t tmw;
     float a[G], b[G], iz[G], gu[G], gv[G];
 };
+template <int BYTE, class W>
+__device__ __forceinline__ float cvt_ubyte(W w) {  // float(byte BYTE of w): one v_cvt_f32_ubyteN, whatever the other bytes hold
+    float f;
+    if (BYTE == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+    if (BYTE == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+    if (BYTE == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    if (BYTE == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
 // Stage B: warp (see the header of this section) + inside test + tap requests.
 template <bool ENERGY_ONLY, int G>
 __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st) {
@@ -627,21 +679,23 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
 // Stage C: lerp-form bilinear interpolation, residual, Jacobian, the 29 sums (`cnt` = the lane's integer count of inside points).
 template <bool HUBER, bool ENERGY_ONLY, int G>
 __device__ __forceinline__ void fused_stage_c(const ImgCtx& c, const JacK& k, const FusedStage<G>& st, float acc[NACC], int& cnt) {
-    uint32_t top[G], bot[G];
+    uint16_t top[G], bot[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         top[g] = st.top[g];
         bot[g] = st.bot[g];
     }
     float t00[G], d0[G], t10[G], d1[G], tp[G], bt[G], im[G], r[G], tm[G];
+    // (spelled as instructions: left to itself the compiler turns float(hi) - float(lo) into shift + SDWA subtract + convert, three
+    // instructions, two of them of the slow class, and moves the zero-extension of a tap word next to its load, i.e. into stage B)
 #pragma unroll
-    for (int g = 0; g < G; ++g) t00[g] = (float)(top[g] & 0xff);
+    for (int g = 0; g < G; ++g) t00[g] = cvt_ubyte<0>(top[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) t10[g] = (float)(bot[g] & 0xff);
+    for (int g = 0; g < G; ++g) t10[g] = cvt_ubyte<0>(bot[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) d0[g] = (float)(top[g] >> 8) - t00[g];
+    for (int g = 0; g < G; ++g) d0[g] = cvt_ubyte<1>(top[g]) - t00[g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) d1[g] = (float)(bot[g] >> 8) - t10[g];
+    for (int g = 0; g < G; ++g) d1[g] = cvt_ubyte<1>(bot[g]) - t10[g];
 #pragma unroll
     for (int g = 0; g < G; ++g) tp[g] = fmaf(st.fa[g], d0[g], t00[g]);
 #pragma unroll
@@ -653,7 +707,7 @@ __device__ __forceinline__ void fused_stage_c(const ImgCtx& c, const JacK& k, co
 #pragma unroll
     for (int g = 0; g < G; ++g) r[g] = st.inside[g] ? im[g] - tm[g] : 0.f;  // selected, never multiplied: outside contributes nothing
 #pragma unroll
-    for (int g = 0; g < G; ++g) cnt += st.inside[g] ? 1 : 0;
+    for (int g = 0; g < G; ++g) cnt += st.inside[g] ? 1 : 0;  // (a wavefront-wide count on the scalar unit, s_bcnt1 of the mask: measured slower)
     float wgt[G], wr[G];
     if (HUBER) {  // extension (not in the reference)
 #pragma unroll
@@ -896,7 +950,7 @@ __device__ __forceinline__ void process_group(const Src& src, const typename Src
 // of a SIMD do not all stall on the same loads at the top of every iteration.
 template <int BLOCK, bool HUBER, bool WRITE_RES, class Src, bool ENERGY_ONLY = false>
 __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, const ImgCtx& c, const Iso& model, float acc[NACC],
-                                                float* residuals, int first = 0) {
+                                                float* residuals, int first = 0, const LmSplitState* pre = nullptr) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
     if constexpr (Src::FUSED) {
@@ -906,12 +960,12 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
         // test (lm_optimizer.rs:227-231) the border rows / columns fall: 1-3 % of the points at the coarsest level, and with them the
         // first energy and the path of the whole LM loop. Only the reference's evaluation order reproduces that, so such an
         // evaluation runs in the exact arithmetic (a handful per pair, mostly at the coarsest level).
-        if (model_near_identity(model)) {
+        if (pre ? fused_ctx_exact(pre) : model_near_identity(model)) {
             eval_accumulate<BLOCK, HUBER, false, typename Src::Base, ENERGY_ONLY>(static_cast<const typename Src::Base&>(src), n_units, c, model, acc,
                                                                                nullptr, first);
             return;
         }
-        const FusedCtx f = make_fused_ctx(c, model);
+        const FusedCtx f = pre ? load_fused_ctx(pre) : make_fused_ctx(c, model);  // (`pre` is a compile-time fact at every call site)
         const JacK jk = make_jack(c);
         int cnt = 0;  // inside points seen by this lane
         for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
@@ -1320,6 +1374,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             st->nb_iter = 0;
             st->n_full = 0;
             st->went_well = went_well ? 1 : 0;
+            if (FUSED && went_well) store_fused_ctx(g, split.n_split - 1, lm_model, st);  // for the workgroups of the first round
             if (went_well) split_append(split, 0, false, pair);
         }
         return;
@@ -1482,9 +1537,13 @@ lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __
         float acc[NACC];
         float* out = ws.partials + ((size_t)pair * ws.chunks + chunk) * 32;
         with_level_source<true, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_units) {
-            const int first = (int)((long long)n_units * chunk / chunks), last = (int)((long long)n_units * (chunk + 1) / chunks);
+            // chunk c = units [c * per + min(c, rem), ...): one 32-bit scalar division (the 64-bit n * c / chunks costs ~150 scalar
+            // instructions apiece, in every workgroup)
+            const unsigned per = (unsigned)n_units / (unsigned)chunks, rem = (unsigned)n_units - per * (unsigned)chunks;
+            const int first = (int)((unsigned)chunk * per + min((unsigned)chunk, rem));
+            const int last = (int)((unsigned)(chunk + 1) * per + min((unsigned)(chunk + 1), rem));
             eval_accumulate<SPLIT_BLOCK, HUBER, false, typename std::remove_cv<typename std::remove_reference<decltype(src)>::type>::type, ENERGY>(
-                src, last, c, model, acc, nullptr, first);
+                src, last, c, model, acc, nullptr, first, FUSED ? st : nullptr);
         });
         if (ENERGY) {
             float e = acc[0], cnt = acc[1];
@@ -1505,7 +1564,7 @@ lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
 // step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
 // (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
-__global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
+__global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
                                                            int next_late) {
     __shared__ float red[32];
     const int n_active = split_n_active(ws, round);
@@ -1628,6 +1687,8 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
             }
             st->nb_iter = nb_iter;
             st->n_full = n_full;
+            // FUSED arithmetic: the context of the evaluation this pair is due next, for all its workgroups (engine.h LmSplitState::fctx)
+            if (again && g.arith == VORS_ARITH_FUSED) store_fused_ctx(g, st->lvl, iso_load(st->phase == 1 ? st->cand : st->model), st);
             // a candidate goes to the energy-only launch of the next round, unless that round is a late one (full evaluations only)
             if (again) split_append(ws, round + 1, st->phase == 1 && !next_late, pair);
         }
@@ -1635,12 +1696,12 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(LmSplitWs ws, vors_pa
     }
 }
 
-void launch_lm_split_step(LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(lm_split_step_kernel, dim3(grid), dim3(64), 0, s, ws, out_stats, round, late, next_late);
+void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(lm_split_step_kernel, dim3(grid), dim3(64), 0, s, g, ws, out_stats, round, late, next_late);
 }
 #else
 // host-side launcher of the (arithmetic-independent) step kernel, defined in the exact object
-void launch_lm_split_step(LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s);
+void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s);
 #endif
 
 #define VORS_LM_KARGS g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats
@@ -1756,7 +1817,7 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
             if (!late && r > 0) hipLaunchKernelGGL((lm_split_eval_kernel<false, true, kFused>), dim3(grid_energy), dim3(SPLIT_BLOCK), 0, s, VORS_SPLIT_KARGS);
         }
 #undef VORS_SPLIT_KARGS
-        launch_lm_split_step(split, out_stats, r, late, next_late, std::max(1, n_pairs / shrink), s);
+        launch_lm_split_step(g, split, out_stats, r, late, next_late, std::max(1, n_pairs / shrink), s);
     }
     // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
     launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
