@@ -9,8 +9,11 @@
 // PARITY STATUS: "parity unpinned" for the tracker as a whole. The reference is pure Rust and there is
 // no Rust toolchain in this image, so the reference binary cannot be run; and the reference's own tests
 // pin only so3/se3 identities and three prune_with_thresh examples. Those ARE checked
-// (tests/test_oracle_kat.py). Everything else is pinned by line-by-line fidelity to the cited files and
-// by ground-truth pose recovery on analytic scenes.
+// (tests/test_oracle_kat.py). Everything else is pinned by line-by-line fidelity to the cited files, by
+// ground-truth pose recovery on analytic scenes, and by first principles in float64
+// (tests/test_oracle_first_principles.py: se3 exp / log = matrix exponential / logarithm, the warp Jacobian =
+// the derivative of the warp, the evaluation sums = their definition, step = the damped normal equations,
+// the inverse-depth pyramid = block means) — which checks the mathematics, not the reference's rounding.
 //
 // Every function cites the reference file:line it follows (paths relative to /root/reference).
 // Build with:  g++ -O3 -std=c++17 -ffp-contract=off -fno-fast-math   (Rust never fuses a*b+c).
