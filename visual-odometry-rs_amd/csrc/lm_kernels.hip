@@ -491,32 +491,36 @@ struct FusedCtx {  // uniform per evaluation, kept in scalar registers
     float h00_2, h00_3, h10_2, h10_3, h20_2, h20_3;     // 2x / 3x the first column: pixels x0+2, x0+3 of a quad
 };
 __device__ __forceinline__ FusedCtx make_fused_ctx(const ImgCtx& c, const Iso& m) {
+    // H = K R K^-1 formed as I + K (R - I) K^-1, all in f32: D = R - I = 2 w [q]x + 2 [q]x^2 (the matrix of nalgebra's UnitQuaternion *
+    // Vector3, lie.h quat_rotate, no unit-norm assumption) has entries of the size of the rotation angle and is formed without
+    // cancellation, so M = K D K^-1 is good to ~1e-6 px in every entry — below the rounding of H itself as 9 floats (h00 x alone carries
+    // 640 * 6e-8 = 4e-5 px). (The earlier f64 formulation of the same thing cost ~250 f64-heavy instructions per thread and evaluation:
+    // a fifth of the per-pair kernel at the coarse levels / in the sparse modes; this is ~70 f32 ones.)
     const Intr& k = c.k;
-    const double qi = m.q.i, qj = m.q.j, qk = m.q.k, qw = m.q.w;
-    // R = I + 2 w [q]x + 2 [q]x^2: the matrix of nalgebra's UnitQuaternion * Vector3 (lie.h quat_rotate), no unit-norm assumption
-    const double r00 = 1.0 - 2.0 * (qj * qj + qk * qk), r01 = 2.0 * (qi * qj - qk * qw), r02 = 2.0 * (qi * qk + qj * qw);
-    const double r10 = 2.0 * (qi * qj + qk * qw), r11 = 1.0 - 2.0 * (qi * qi + qk * qk), r12 = 2.0 * (qj * qk - qi * qw);
-    const double r20 = 2.0 * (qi * qk - qj * qw), r21 = 2.0 * (qj * qk + qi * qw), r22 = 1.0 - 2.0 * (qi * qi + qj * qj);
-    const double fu = k.fu, fv = k.fv, sk = k.skew, cu = k.cu, cv = k.cv;
-    // K R (camera.rs:126-132)
-    const double a00 = fu * r00 + sk * r10 + cu * r20, a01 = fu * r01 + sk * r11 + cu * r21, a02 = fu * r02 + sk * r12 + cu * r22;
-    const double a10 = fv * r10 + cv * r20, a11 = fv * r11 + cv * r21, a12 = fv * r12 + cv * r22;
+    const float qi = m.q.i, qj = m.q.j, qk = m.q.k, qw = m.q.w;
+    const float d00 = -2.0f * fmaf(qj, qj, qk * qk), d01 = 2.0f * fmaf(qi, qj, -(qk * qw)), d02 = 2.0f * fmaf(qi, qk, qj * qw);
+    const float d10 = 2.0f * fmaf(qi, qj, qk * qw), d11 = -2.0f * fmaf(qi, qi, qk * qk), d12 = 2.0f * fmaf(qj, qk, -(qi * qw));
+    const float d20 = 2.0f * fmaf(qi, qk, -(qj * qw)), d21 = 2.0f * fmaf(qj, qk, qi * qw), d22 = -2.0f * fmaf(qi, qi, qj * qj);
+    const float fu = k.fu, fv = k.fv, sk = k.skew, cu = k.cu, cv = k.cv;
+    // K D (camera.rs:126-132)
+    const float a00 = fmaf(fu, d00, fmaf(sk, d10, cu * d20)), a01 = fmaf(fu, d01, fmaf(sk, d11, cu * d21)), a02 = fmaf(fu, d02, fmaf(sk, d12, cu * d22));
+    const float a10 = fmaf(fv, d10, cv * d20), a11 = fmaf(fv, d11, cv * d21), a12 = fmaf(fv, d12, cv * d22);
     // ... K^-1 (camera.rs:135-140): col0 = A0 / fu, col1 = (A1 - s col0) / fv, col2 = A2 - cu col0 - cv col1
-    const double ifu = c.inv_fu_d != 0.0 ? c.inv_fu_d : 1.0 / fu, ifv = c.inv_fv_d != 0.0 ? c.inv_fv_d : 1.0 / fv;  // (uniform branch)
-    const double h00 = a00 * ifu, h10 = a10 * ifu, h20 = r20 * ifu;
-    const double h01 = (a01 - sk * h00) * ifv, h11 = (a11 - sk * h10) * ifv, h21 = (r21 - sk * h20) * ifv;
-    const double h02 = a02 - cu * h00 - cv * h01, h12 = a12 - cu * h10 - cv * h11, h22 = r22 - cu * h20 - cv * h21;
-    const double tx = m.t.x, ty = m.t.y, tz = m.t.z;
+    const float ifu = c.inv_fu_d != 0.0 ? c.inv_fu : 1.0f / fu, ifv = c.inv_fu_d != 0.0 ? c.inv_fv : 1.0f / fv;  // (uniform branch)
+    const float m00 = a00 * ifu, m10 = a10 * ifu, m20 = d20 * ifu;
+    const float m01 = fmaf(-sk, m00, a01) * ifv, m11 = fmaf(-sk, m10, a11) * ifv, m21 = fmaf(-sk, m20, d21) * ifv;
+    const float m02 = fmaf(-cv, m01, fmaf(-cu, m00, a02)), m12 = fmaf(-cv, m11, fmaf(-cu, m10, a12)), m22 = fmaf(-cv, m21, fmaf(-cu, m20, d22));
+    const float tx = m.t.x, ty = m.t.y, tz = m.t.z;
     FusedCtx f;
-    f.h00 = uniform_f((float)h00); f.h01 = uniform_f((float)h01); f.h02 = uniform_f((float)h02);
-    f.h10 = uniform_f((float)h10); f.h11 = uniform_f((float)h11); f.h12 = uniform_f((float)h12);
-    f.h20 = uniform_f((float)h20); f.h21 = uniform_f((float)h21); f.h22 = uniform_f((float)h22);
-    f.m0 = uniform_f((float)(fu * tx + sk * ty + cu * tz));
-    f.m1 = uniform_f((float)(fv * ty + cv * tz));
-    f.m2 = uniform_f((float)tz);
-    f.h00_2 = uniform_f((float)(2.0 * h00)); f.h00_3 = uniform_f((float)(3.0 * h00));
-    f.h10_2 = uniform_f((float)(2.0 * h10)); f.h10_3 = uniform_f((float)(3.0 * h10));
-    f.h20_2 = uniform_f((float)(2.0 * h20)); f.h20_3 = uniform_f((float)(3.0 * h20));
+    f.h00 = uniform_f(1.0f + m00); f.h01 = uniform_f(m01); f.h02 = uniform_f(m02);
+    f.h10 = uniform_f(m10); f.h11 = uniform_f(1.0f + m11); f.h12 = uniform_f(m12);
+    f.h20 = uniform_f(m20); f.h21 = uniform_f(m21); f.h22 = uniform_f(1.0f + m22);
+    f.m0 = uniform_f(fmaf(fu, tx, fmaf(sk, ty, cu * tz)));
+    f.m1 = uniform_f(fmaf(fv, ty, cv * tz));
+    f.m2 = uniform_f(tz);
+    f.h00_2 = uniform_f(2.0f * f.h00); f.h00_3 = uniform_f(3.0f * f.h00);
+    f.h10_2 = uniform_f(2.0f * f.h10); f.h10_3 = uniform_f(3.0f * f.h10);
+    f.h20_2 = uniform_f(2.0f * f.h20); f.h20_3 = uniform_f(3.0f * f.h20);
     return f;
 }
 // Workgroup-uniform: would this model move some pixel by less than ~1e-2 px?  (|rotation| <= 1e-5 rad, |t| <= 1e-6 m.)
