@@ -1063,6 +1063,80 @@ __device__ __forceinline__ void block_reduce(const float acc[NACC], LmShared& s,
 }
 
 // step(): lm_optimizer.rs:123-136, by ONE lane on the kept state's sums; result broadcast through LDS.
+// FUSED arithmetic: step() (lm_optimizer.rs:123-136) with the 6x6 Cholesky factor scaled by reciprocal square roots and the two
+// triangular solves by the stored reciprocals (6 v_rsq + multiplies instead of 6 IEEE square roots and 33 IEEE divisions, FMAs
+// contracted), and from_quaternion through one v_rsq. The one-lane step is ~40 % of the instructions the per-pair kernel issues in the
+// sparse modes (a few hundred points per evaluation); this form is about half as long. Same pivot rule (a pivot that is not > 0 fails).
+__device__ __forceinline__ bool lm_step_fast(const float* h, const float* g, const Iso& model, float lm_coef, Iso* out) {
+    float a[6][6], inv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[r][c] = h[r * 6 + c];
+    const float scale = 1.0f + lm_coef;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r][r] *= scale;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+#pragma unroll
+            for (int i = j; i < 6; ++i) a[i][j] = fmaf(-a[j][k], a[i][k], a[i][j]);
+        }
+        const float diag = a[j][j];
+        ok = ok && (diag > 0.0f);
+        inv[j] = __builtin_amdgcn_rsqf(diag);
+        a[j][j] = diag * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) a[i][j] *= inv[j];
+    }
+    if (!ok) return false;
+    float b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = g[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        b[i] *= inv[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) b[k] = fmaf(-b[i], a[k][i], b[k]);
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        float acc = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) acc = fmaf(-a[k][i], b[k], acc);
+        b[i] = acc * inv[i];
+    }
+    // se3::exp (se3.rs:65-95) as in lie.h, from_quaternion by reciprocal square root
+    const float vx = b[0], vy = b[1], vz = b[2], wx = b[3], wy = b[4], wz = b[5];
+    const float theta_2 = fmaf(wz, wz, fmaf(wy, wy, wx * wx));
+    float real_factor, imag_factor, c1, c2;
+    if (theta_2 < 1e-2f * 1e-2f) {
+        real_factor = fmaf(-0.125f, theta_2, 1.0f);
+        imag_factor = fmaf(-(1.0f / 48.0f), theta_2, 0.5f);
+        c1 = fmaf(-(1.0f / 24.0f), theta_2, 0.5f);
+        c2 = fmaf(-(1.0f / 120.0f), theta_2, 1.0f / 6.0f);
+    } else {
+        const float theta = sqrtf(theta_2), half_theta = 0.5f * theta, rt2 = 1.0f / theta_2;
+        real_factor = cosf(half_theta);
+        imag_factor = sinf(half_theta) / theta;
+        const float sh = sinf(half_theta);
+        c1 = 2.0f * sh * sh * rt2;  // (1 - cos t) / t^2 without the cancellation
+        c2 = (theta - sinf(theta)) * rt2 / theta;
+    }
+    const float w11 = wx * wx, w12 = wx * wy, w13 = wx * wz, w22 = wy * wy, w23 = wy * wz, w33 = wz * wz;
+    Iso dw;
+    dw.t.x = fmaf(fmaf(c2, -w22 - w33, 1.0f), vx, fmaf(fmaf(c2, w12, -c1 * wz), vy, fmaf(c2, w13, c1 * wy) * vz));
+    dw.t.y = fmaf(fmaf(c2, w12, c1 * wz), vx, fmaf(fmaf(c2, -w11 - w33, 1.0f), vy, fmaf(c2, w23, -c1 * wx) * vz));
+    dw.t.z = fmaf(fmaf(c2, w13, -c1 * wy), vx, fmaf(fmaf(c2, w23, c1 * wx), vy, fmaf(c2, -w11 - w22, 1.0f) * vz));
+    const Quat q{imag_factor * wx, imag_factor * wy, imag_factor * wz, real_factor};
+    const float rn = __builtin_amdgcn_rsqf(quat_norm_squared(q));
+    dw.q = Quat{q.i * rn, q.j * rn, q.k * rn, q.w * rn};
+    *out = renormalize(iso_mul(model, iso_inverse(dw)));
+    return true;
+}
+template <bool FAST>
 __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso& model, float lm_coef) {
     if (threadIdx.x == 0) {
         const float* a = s.sums[cur];
@@ -1079,7 +1153,7 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
                 ++k;
             }
         Iso cand;
-        const bool ok = lm_step(h, g, model, lm_coef, &cand);
+        const bool ok = FAST ? lm_step_fast(h, g, model, lm_coef, &cand) : lm_step(h, g, model, lm_coef, &cand);
         iso_store(cand, s.cand);
         s.cand[7] = ok ? 1.0f : 0.0f;
     }
@@ -1123,7 +1197,7 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
     for (;;) {
         if (!have_cand) {
             nb_iter += 1;
-            solve_step_lane0(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
+            solve_step_lane0<Src::FUSED>(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
             if (uniform_f(s.cand[7]) == 0.0f) return false;
             cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
         }
@@ -1673,7 +1747,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws,
                         ++k;
                     }
                 Iso cand;
-                if (lm_step(h, gr, cur_model, lm_coef, &cand)) {
+                if (g.arith == VORS_ARITH_FUSED ? lm_step_fast(h, gr, cur_model, lm_coef, &cand) : lm_step(h, gr, cur_model, lm_coef, &cand)) {
                     iso_store(cand, st->cand);
                     st->phase = 1;
                     again = true;
