@@ -7,9 +7,11 @@ import vors_amd as V
 from oracle import oracle as O
 rows, cols, L = 480, 640, 6
 intr = O.scaled_intrinsics(rows, cols)
-for mode, n in ((0, 512), (1, 96)):
+NS = [int(x) for x in os.environ.get("PAIRS", "512,96").split(",")]
+ARITH = int(os.environ.get("ARITH", "0"))  # 0 EXACT, 1 FUSED
+for mode, n in ((0, NS[0]), (1, NS[1])):
     kg, kd, cg, _, gt = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
-    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=ARITH)
     b = V.Batch(cfg, n, rows, cols)
     poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(n)
     b.track_pairs(kg, kd, cg, poses, status, stats); torch.cuda.synchronize()
@@ -19,7 +21,21 @@ for mode, n in ((0, 512), (1, 96)):
     err = np.abs(poses.cpu().numpy() - ref["poses"]).max(axis=1)
     same_it = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1)
     q = np.quantile(err, [0.5, 0.9, 0.99, 1.0])
-    print(f"mode {mode} n {n}: |pose diff| median {q[0]:.2e} p90 {q[1]:.2e} p99 {q[2]:.2e} max {q[3]:.2e}; >1e-5: {(err>1e-5).sum()} >1e-4: {(err>1e-4).sum()}; "
+    print(f"arith {ARITH} mode {mode} n {n}: |pose diff| median {q[0]:.2e} p90 {q[1]:.2e} p99 {q[2]:.2e} max {q[3]:.2e}; >1e-5: {(err>1e-5).sum()} >1e-4: {(err>1e-4).sum()}; "
           f"identical iteration counts {same_it.mean():.1%}; status equal {(status.cpu().numpy()==ref['status']).all()}; oracle {time.time()-t0:.1f}s")
+    kgn, kdn, cgn = kg.cpu().numpy(), kd.cpu().numpy().view(np.uint16), cg.cpu().numpy()
+    for v in os.environ.get("VARIANTS", "acc64,nalg1").split(","):  # the oracle against its own sensitivity builds, same pairs
+        if not v: continue
+        rv = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kgn, kdn, cgn, n_threads=os.cpu_count(), variant=v)
+        ev = np.abs(rv["poses"] - ref["poses"]).max(axis=1)
+        qv = np.quantile(ev, [0.5, 0.99, 1.0])
+        both = ((ev > 1e-4) & (err > 1e-4)).sum()
+        print(f"   oracle[{v}] vs oracle: median {qv[0]:.2e} p99 {qv[1]:.2e} max {qv[2]:.2e}; >1e-5: {(ev>1e-5).sum()} >1e-4: {(ev>1e-4).sum()} (of which also GPU outliers: {both})")
+    gtn = gt.cpu().numpy()
+    inv = lambda P: np.stack([O.iso_inverse(p) for p in P])  # tracked pose of the current frame -> keyframe-to-current model (what gt holds)
+    eg, eo = np.abs(inv(poses.cpu().numpy()) - gtn).max(axis=1), np.abs(inv(ref["poses"]) - gtn).max(axis=1)
+    out = err > 1e-4
+    print(f"   vs ground truth, all pairs: GPU median {np.median(eg):.2e} max {eg.max():.2e}; oracle median {np.median(eo):.2e} max {eo.max():.2e}; "
+          f"on the {out.sum()} outlier pairs: GPU median {np.median(eg[out]) if out.any() else 0:.2e}, oracle median {np.median(eo[out]) if out.any() else 0:.2e}")
     bad = np.argsort(-err)[:3]
     for i in bad: print("   pair", i, "err", err[i], "gpu iters", st["nb_iter"][i][:L], "oracle", ref["nb_iter"][i])
