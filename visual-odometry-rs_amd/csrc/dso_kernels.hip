@@ -631,12 +631,400 @@ static void keyframe_from_mask(const Geom& g, Pyramid kf, const uint16_t* depth,
     hipLaunchKernelGGL(generic_build_records_kernel, dim3(GENERIC_BUILD_WGS * g.L, n_pairs), dim3(256), 0, s, g, kf.level0, kf.upper, depth, mask, pp,
                        rec);
 }
+// ------------------------------------------------------------------------------------------------------------
+// Sparse form of the generic-mask path (the DSO selector keeps ~0.7 % of the pixels; going through dense per-level planes cost
+// 4.9 ms per 4096 pairs against 1.1 ms for the whole coarse-to-fine keyframe stage). One workgroup per pair:
+//   A  one pass over the level-0 plane (pick stamps -> final mask bytes, written out; or the mask itself), the usable pixels
+//      (mask && depth != 0) appended as (Morton code of (x, y) << 16 | depth) — bit 0 of the code is y's bit 0, bit 1 x's bit 0, ...
+//   B  bitonic sort of those words (LDS up to 4096 of them, global scratch beyond). In Morton order the children of EVERY node of
+//      EVERY level are contiguous and appear as a = (2i, 2j), b = (2i+1, 2j), c = (2i, 2j+1), d = (2i+1, 2j+1): the order
+//      inverse_depth.rs:81-98 fuses them in.
+//   C  level l from level l - 1: a segmented fusion over runs of equal code >> 2 (strategy_dso_mean on the known children; a parent
+//      outside the halved shape — odd trailing row / column, multires.rs:67-88 — does not exist), compacted in order.
+//   D  per level the 12-byte records (coordinates, inverse depth, template + integer gradient gathered from the pyramid).
+// Same values as the plane path, bit for bit; the lists come out in Morton order instead of raster order (the LM sums differ in
+// their last bits only). Scratch: the (otherwise unused) pixel planes of the pair.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t morton_part(uint32_t v) {
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton_compact(uint32_t k) {
+    k &= 0x55555555u;
+    k = (k | (k >> 1)) & 0x33333333u;
+    k = (k | (k >> 2)) & 0x0F0F0F0Fu;
+    k = (k | (k >> 4)) & 0x00FF00FFu;
+    k = (k | (k >> 8)) & 0x0000FFFFu;
+    return k;
+}
+constexpr int SPARSE_LDS_N = 4096;  // entries of the LDS form: sort words 32 KB + (key, inverse depth, weight) 48 KB: two workgroups per CU
+// Exclusive position of a flagged thread among the flagged threads of the workgroup (1024 threads), plus their number.
+// Two barriers; `s_wave` is workgroup scratch.
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+    __syncthreads();  // (s_wave may still be read from the previous call)
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int pos = before, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        pos += w < wave ? s_wave[w] : 0;
+        tot += s_wave[w];
+    }
+    *total = tot;
+    return pos;
+}
+// Phase A over the pixels [p0, p1) of the level-0 plane of one pair (whole rows): final mask bytes out, usable pixels appended to `gsort`.
+struct SparseScan {
+    const uint8_t* src;
+    uint8_t* mout;
+    const uint16_t* dp;
+    uint64_t* gsort;
+    DsoState st;
+    int from_stamps, cols0, cap_n;
+    bool vec;
+};
+__device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1, int* s_n) {
+    for (int t0 = p0 + (int)threadIdx.x * 16; t0 < p1; t0 += 1024 * 16) {
+        uint32_t bits = 0;
+        if (q.vec) {
+            const uint4 pk = *reinterpret_cast<const uint4*>(q.src + t0);
+            if ((pk.x | pk.y | pk.z | pk.w) != 0) {
+                const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int bq = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+                    if (bq && (!q.from_stamps || dso_final_mask(q.st, bq, t0 + k, q.cols0))) bits |= 1u << k;
+                }
+            }
+            if (q.from_stamps) {
+                uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) o[k >> 2] |= ((bits >> k) & 1u) << (8 * (k & 3));
+                *reinterpret_cast<uint4*>(q.mout + t0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int k = 0; k < 16 && t0 + k < p1; ++k) {
+                const int bq = q.src[t0 + k];
+                const bool m = bq && (!q.from_stamps || dso_final_mask(q.st, bq, t0 + k, q.cols0));
+                if (m) bits |= 1u << k;
+                if (q.from_stamps) q.mout[t0 + k] = m ? 1 : 0;
+            }
+        }
+        uint32_t usable = 0;
+        for (uint32_t bb = bits; bb; bb &= bb - 1) {
+            const int k = __ffs(bb) - 1;
+            if (q.dp[t0 + k] != 0) usable |= 1u << k;
+        }
+        if (usable) {
+            int pos = atomicAdd(s_n, __popc(usable));
+            for (uint32_t bb = usable; bb; bb &= bb - 1, ++pos) {
+                const int k = __ffs(bb) - 1, t = t0 + k, y = t / q.cols0, x = t - y * q.cols0;
+                if (pos < q.cap_n) q.gsort[pos] = ((uint64_t)(morton_part((uint32_t)y) | (morton_part((uint32_t)x) << 1)) << 16) | q.dp[t];
+            }
+        }
+    }
+}
+// Phases B-D on n0 appended words. `a` (sort words) and `key` (three arrays of `cap_set`) are EITHER the LDS buffers OR the pair's global
+// scratch; the function is inlined once per case so that the LDS case compiles to ds_ instructions (not flat ones).
+__device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, const uint8_t* kfu, int pair, const uint64_t* gsort, int n0,
+                                             uint64_t* a, bool copy_in, uint32_t* key, int cap_set, const Records& rec, int* s_wave, int* s_out,
+                                             uint32_t* s_prev) {
+    const int tid = threadIdx.x;
+    int P = 2;
+    while (P < n0) P <<= 1;
+    if (copy_in)
+        for (int i = tid; i < P; i += 1024) a[i] = i < n0 ? gsort[i] : ~0ull;
+    else
+        for (int i = n0 + tid; i < P; i += 1024) a[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 1024) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const uint64_t x = a[i], y = a[q];
+                    if ((x > y) == ((i & k) == 0)) {
+                        a[i] = y;
+                        a[q] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // One set of (key, inverse depth, weight) arrays, rewritten in place level by level: a pass reads its inputs into registers, meets
+    // at a barrier, then writes (the outputs of a level land at or below inputs already consumed).
+    float* dd = reinterpret_cast<float*>(key + cap_set);
+    float* vv = reinterpret_cast<float*>(key + 2 * cap_set);
+    for (int i = tid; i < n0; i += 1024) {
+        const uint64_t c = a[i];
+        key[i] = (uint32_t)(c >> 16);
+        dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);  // from_depth, inverse_depth.rs:24-29
+        vv[i] = g.idepth_variance;
+    }
+    __syncthreads();
+    int n = n0;
+    for (int l = 0; l < g.L; ++l) {
+        if (l > 0) {
+            const int rows = g.lv[l].rows, cols = g.lv[l].cols;
+            int n_new = 0;
+            if (tid == 0) *s_prev = 0xffffffffu;
+            __syncthreads();
+            for (int base = 0; base < n; base += 1024) {
+                const int i = base + tid;
+                bool head = false;
+                uint32_t pk = 0;
+                float fd = 0.f, fv = 0.f;
+                const uint32_t prev_chunk_last = *s_prev;  // key >> 2 of the entry before this chunk (overwritten by now, perhaps)
+                if (i < n) {
+                    pk = key[i] >> 2;
+                    const uint32_t before = tid == 0 ? prev_chunk_last : (key[max(i - 1, 0)] >> 2);  // (clamped: the load may be issued for i == 0 too)
+                    head = before != pk;
+                    if (head) head = (int)morton_compact(pk >> 1) < cols && (int)morton_compact(pk) < rows;
+                    if (head) {
+                        // strategy_dso_mean over the known children, in [a, b, c, d] order (inverse_depth.rs:81-98)
+                        int m = 1;
+                        while (m < 4 && i + m < n && (key[i + m] >> 2) == pk) ++m;
+                        if (m == 1) {
+                            fd = dd[i];
+                            fv = vv[i];
+                        } else {
+                            float sv = vv[i] + vv[i + 1], sd = dd[i] * vv[i] + dd[i + 1] * vv[i + 1];
+                            if (m > 2) {
+                                sv += vv[i + 2];
+                                sd += dd[i + 2] * vv[i + 2];
+                            }
+                            if (m > 3) {
+                                sv += vv[i + 3];
+                                sd += dd[i + 3] * vv[i + 3];
+                            }
+                            fv = sv;
+                            fd = sd / sv;
+                        }
+                    }
+                }
+                int total;
+                const int pos = n_new + block_rank(head, s_wave, &total);  // (its barriers separate this chunk's reads from its writes)
+                if (i < n && (tid == 1023 || i == n - 1)) *s_prev = pk;
+                if (head) {
+                    key[pos] = pk;
+                    dd[pos] = fd;
+                    vv[pos] = fv;
+                }
+                n_new += total;
+                __syncthreads();
+            }
+            n = n_new;
+        }
+        // records of level l (engine.h SlimRec), appended behind those of the earlier groups of bands
+        const int cap = g.lv[l].n_slots, o0 = s_out[l], n_out = max(0, min(n, cap - o0));
+        SlimRec* out = rec.S + (size_t)pair * g.slots_total + g.lv[l].slot_off + o0;
+        for (int i = tid; i < n_out; i += 1024) {
+            const uint32_t k2 = key[i];
+            const int x = (int)morton_compact(k2 >> 1), y = (int)morton_compact(k2);
+            int gx, gy, tm;
+            grad_tmpl_at(g, kf0, kfu, pair, l, x, y, &gx, &gy, &tm);
+            out[i] = SlimRec{(uint32_t)x | ((uint32_t)y << 16), dd[i], slim_pack_tg(tm, gx, gy)};
+        }
+        __syncthreads();
+        if (tid == 0) s_out[l] = o0 + n_out;
+        __syncthreads();
+    }
+}
+// Phase A for the whole batch at memory speed: many workgroups per pair, the usable pixels appended to the pair's scratch in any order
+// (phase B sorts them), their number in `counts[pair]` (zeroed by the launcher). A pair with more than `cap_n` of them is scanned again,
+// band by band, by its own workgroup below.
+constexpr int SCAN_U = 4;  // 16-pixel groups per thread of the scan kernel (64 consecutive pixels)
+__global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
+                                                                int from_stamps, PixelPlanes pp, int cap_n) {
+    // 64 consecutive pixels per thread (a wavefront that does less is bound by its own launch); the workgroup's usable pixels get ONE
+    // reservation in the pair's list (a prefix sum over the workgroup, one global atomic); the 16 depths under a group with a pick come
+    // in one round trip.
+    __shared__ int s_wave[4], s_base;
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S0 = g.S0, cols0 = g.lv[0].cols;
+    const uint8_t* src = (from_stamps ? ws.picked : mask) + (size_t)pair * S0;
+    uint8_t* mout = mask + (size_t)pair * S0;
+    const uint16_t* dp = depth + (size_t)pair * S0;
+    uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
+    const bool vec = cols0 % 16 == 0 && S0 % 16 == 0;
+    const int tb = (blockIdx.x * 256 + tid) * (16 * SCAN_U);
+    DsoState st{};
+    if (from_stamps) st = ws.state[pair];
+    uint32_t usable[SCAN_U];
+    int mine = 0;
+    if (vec) {
+        uint4 pk[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) pk[u] = (tb + 16 * u < S0) ? *reinterpret_cast<const uint4*>(src + tb + 16 * u) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) {
+            const int t0 = tb + 16 * u;
+            const uint4 p4 = pk[u];
+            uint32_t bits = 0;
+            if ((p4.x | p4.y | p4.z | p4.w) != 0) {
+                const uint32_t w[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int bq = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+                    if (bq && (!from_stamps || dso_final_mask(st, bq, t0 + k, cols0))) bits |= 1u << k;
+                }
+            }
+            if (from_stamps && t0 < S0) {
+                uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) o[k >> 2] |= ((bits >> k) & 1u) << (8 * (k & 3));
+                *reinterpret_cast<uint4*>(mout + t0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            uint32_t us = 0;
+            if (bits) {  // the 16 depths under the group in one round trip
+                const uint4 d0 = *reinterpret_cast<const uint4*>(dp + t0), d1 = *reinterpret_cast<const uint4*>(dp + t0 + 8);
+                const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) us |= (((dw[j] & 0xffffu) != 0 ? 1u : 0u) | ((dw[j] >> 16) != 0 ? 2u : 0u)) << (2 * j);
+                us &= bits;
+            }
+            usable[u] = us;
+            mine += __popc(us);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) {
+            const int t0 = tb + 16 * u;
+            uint32_t us = 0;
+            for (int k = 0; k < 16 && t0 + k < S0; ++k) {
+                const int bq = src[t0 + k];
+                const bool m = bq && (!from_stamps || dso_final_mask(st, bq, t0 + k, cols0));
+                if (m && dp[t0 + k] != 0) us |= 1u << k;
+                if (from_stamps) mout[t0 + k] = m ? 1 : 0;
+            }
+            usable[u] = us;
+            mine += __popc(us);
+        }
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        before += w < wave ? s_wave[w] : 0;
+        total += s_wave[w];
+    }
+    if (tid == 0) s_base = total ? atomicAdd(pp.counts + (size_t)pair * pp.chunks_total, total) : 0;
+    __syncthreads();
+    if (mine == 0) return;
+    int pos = s_base + before;
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u) {
+        if (usable[u] == 0) continue;
+        const int t0 = tb + 16 * u, y0 = t0 / cols0, x0 = t0 - y0 * cols0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (!((usable[u] >> k) & 1u)) continue;
+            int x = x0 + k, y = y0;
+            if (x >= cols0) {  // (only when a 16-pixel group straddles rows: cols % 16 != 0)
+                y += x / cols0;
+                x = x % cols0;
+            }
+            if (pos < cap_n) gsort[pos] = ((uint64_t)(morton_part((uint32_t)y) | (morton_part((uint32_t)x) << 1)) << 16) | dp[t0 + k];
+            ++pos;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                    const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
+                                                                    int from_stamps, PixelPlanes pp, Records rec, int cap_n) {
+    __shared__ uint64_t lds_sort[SPARSE_LDS_N];
+    __shared__ uint32_t lds_set[3 * SPARSE_LDS_N];
+    __shared__ int s_n, s_wave[16], s_out[VORS_MAX_LEVELS];
+    __shared__ uint32_t s_prev;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int S0 = g.S0, rows0 = g.lv[0].rows, cols0 = g.lv[0].cols;
+    uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
+    uint32_t* gset = reinterpret_cast<uint32_t*>(pp.iz + (size_t)pair * pp.stride);
+    SparseScan q;
+    q.src = (from_stamps ? ws.picked : mask) + (size_t)pair * S0;
+    q.mout = mask + (size_t)pair * S0;
+    q.dp = depth + (size_t)pair * S0;
+    q.gsort = gsort;
+    q.st = DsoState{};
+    if (from_stamps) q.st = ws.state[pair];
+    q.from_stamps = from_stamps;
+    q.cols0 = cols0;
+    q.cap_n = cap_n;
+    q.vec = cols0 % 16 == 0 && S0 % 16 == 0;  // (band starts are then multiples of 16 as well)
+    if (tid < VORS_MAX_LEVELS) s_out[tid] = 0;
+    // The whole plane in one go when its usable pixels fit the scratch (any selector's mask does). Otherwise in groups of BANDS of whole
+    // tile rows (2^(L-1) image rows: no node of any level has children in two bands) — as many bands per group as fit; a band alone always
+    // fits (launch rule).
+    const int band_rows = 1 << (g.L - 1), n_bands = (rows0 + band_rows - 1) / band_rows;
+    bool all_at_once = true;
+    int band = 0;
+    while (band < n_bands) {
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        int n0 = 0;
+        if (all_at_once) {
+            n0 = pp.counts[(size_t)pair * pp.chunks_total];  // mask_sparse_scan_kernel has been over the whole plane
+            if (n0 > cap_n) {
+                all_at_once = false;
+                continue;
+            }
+            band = n_bands;
+        } else {
+            const int first = band;
+            for (; band < n_bands; ++band) {
+                sparse_scan(q, band * band_rows * cols0, min(S0, (band + 1) * band_rows * cols0), &s_n);
+                __syncthreads();
+                const int n_now = s_n;
+                __syncthreads();
+                if (n_now > cap_n) break;  // this band does not fit behind the earlier ones: they go first, it is scanned again
+                n0 = n_now;
+            }
+            if (band == first) {  // (a band alone overflowing: excluded by the launch rule; skip it rather than spin)
+                ++band;
+                continue;
+            }
+        }
+        if (n0 == 0) continue;
+        if (n0 <= SPARSE_LDS_N)
+            sparse_flush(g, kf0, kfu, pair, gsort, n0, lds_sort, true, lds_set, SPARSE_LDS_N, rec, s_wave, s_out, &s_prev);
+        else
+            sparse_flush(g, kf0, kfu, pair, gsort, n0, gsort, false, gset, cap_n, rec, s_wave, s_out, &s_prev);
+    }
+    __syncthreads();
+    if (tid < g.L) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + tid] = s_out[tid];
+}
+
 // DSO-style selection + keyframe precompute. When the shape allows it (level 1 exists, cols % 16 == 0, rows even) the mask is
 // finalized inside the level-1 inverse-depth pass (one pass over the level-0 planes instead of three).
 void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
                          hipStream_t s) {
     const bool fused = g.L >= 2 && g.lv[0].cols % 16 == 0 && g.lv[0].rows % 2 == 0;
     launch_dso_selection(g, kf, ws, n_pairs, s);
+    // Sparse form whenever the pair's pixel planes (its scratch) hold every pixel of one band of tile rows (then any mask works: denser
+    // ones go through in several groups of bands); VORS_DSO_PLANES=1 forces the plane path.
+    int cap_n = 1;
+    while (2 * cap_n <= pp.stride / 3) cap_n *= 2;
+    static const bool force_planes = getenv("VORS_DSO_PLANES") && atoi(getenv("VORS_DSO_PLANES")) != 0;
+    if (!force_planes && cap_n >= (1 << (g.L - 1)) * g.lv[0].cols && g.lv[0].cols < 65536 && g.lv[0].rows < 65536) {  // a band alone fits
+        (void)hipMemsetAsync(pp.counts, 0, (size_t)n_pairs * pp.chunks_total * sizeof(int), s);
+        hipLaunchKernelGGL(mask_sparse_scan_kernel, dim3((g.S0 + 256 * 16 * SCAN_U - 1) / (256 * 16 * SCAN_U), n_pairs), dim3(256), 0, s, g, depth, mask, ws, 1, pp, cap_n);
+        hipLaunchKernelGGL(mask_sparse_records_kernel, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, mask, ws, 1, pp, rec, cap_n);
+        return;
+    }
     if (!fused) hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 4095) / 4096, n_pairs), dim3(256), 0, s, g, ws, mask);
     keyframe_from_mask(g, kf, depth, mask, pp, rec, fused ? &ws : nullptr, n_pairs, s);
 }
