@@ -1,0 +1,60 @@
+"""The sparse form of the DSO / generic-mask keyframe path (dso_kernels.hip: Morton-sorted pick list, segmented fusion per level) against
+the plane path it replaces (per-level inverse-depth planes, count / compact / records), which VORS_DSO_PLANES=1 still selects: the usable
+candidates of every level must be the same set with bit-identical inverse depths, templates and gradients. The environment switch is
+read once per process, so each path runs in its own interpreter. GPU only.
+
+Shapes: the bench shape; an odd shape (trailing row / column without parents); a small image where the selector's recursion ends with a
+mask far denser than its target (the pick list does not fit the pair's scratch in one go: groups of bands)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = r"""
+import sys, os
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "visual-odometry-rs_amd"))
+import numpy as np, torch
+import vors_amd as V
+rows, cols, L, n, out = {rows}, {cols}, {L}, 3, {out!r}
+intr = V.scaled_intrinsics(rows, cols)
+kg, kd, cg, _, gt = V.synth_render_pairs((1 << 63) | 0x5EEDD500, n, rows, cols, intr)
+b = V.Batch(V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=2), n, rows, cols)
+poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
+b.track_pairs(kg, kd, cg, poses, status); torch.cuda.synchronize()
+res = dict(poses=poses.cpu().numpy(), status=status.cpu().numpy())
+for p in range(n):
+    for l in range(L):
+        xy, iz, jac, tm = b.points(p, l)
+        o = np.lexsort((xy[:, 0], xy[:, 1]))
+        res[f"xy_{{p}}_{{l}}"] = xy[o]; res[f"iz_{{p}}_{{l}}"] = iz[o].view(np.uint32); res[f"jac_{{p}}_{{l}}"] = jac[o].view(np.uint32); res[f"tm_{{p}}_{{l}}"] = tm[o]
+np.savez(out, **res)
+"""
+
+
+def run(tmp_path, tag, planes, rows, cols, L):
+    out = str(tmp_path / f"{tag}.npz")
+    env = dict(os.environ)
+    env["VORS_DSO_PLANES"] = "1" if planes else "0"
+    subprocess.run([sys.executable, "-c", DUMP.format(root=ROOT, rows=rows, cols=cols, L=L, out=out)], check=True, env=env, timeout=300)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("rows,cols,L", [(480, 640, 6), (121, 163, 4), (96, 128, 3), (64, 96, 2)])
+def test_sparse_form_equals_plane_path(tmp_path, rows, cols, L):
+    a, b = run(tmp_path, "sparse", False, rows, cols, L), run(tmp_path, "planes", True, rows, cols, L)
+    assert (a["status"] == b["status"]).all()
+    n_lvl0 = []
+    for key in a.files:
+        if key in ("poses", "status"):
+            continue
+        assert a[key].shape == b[key].shape and (a[key] == b[key]).all(), key
+        if key.startswith("xy_") and key.endswith("_0"):
+            n_lvl0.append(len(a[key]))
+    print(f"[{cols}x{rows} L{L}] level-0 candidates per pair {n_lvl0}; max pose difference between the two list orders "
+          f"{np.abs(a['poses'] - b['poses']).max():.2e}")
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-4  # same candidates, different order of summation
