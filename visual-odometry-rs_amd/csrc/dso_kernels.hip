@@ -299,6 +299,26 @@ __device__ __forceinline__ uint8_t dso_final_mask(const DsoState& st, int stamp,
     }
     return m ? 1 : 0;
 }
+// Final-mask bits of the 16 stamps in w[0..3] (pixels t0 .. t0 + 15): the cheap test for all 16, then the sub-sampling hash only for
+// the stamps that passed it, one per trip (a wavefront then pays the hash max-picks-per-lane times, not 16 times).
+__device__ __forceinline__ uint32_t dso_final_bits16(const DsoState& st, const uint32_t w[4], int t0, int cols) {
+    uint32_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int stamp = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+        if ((stamp & 3) != 0 && (stamp >> 2) == st.final_round) cand |= 1u << k;
+    }
+    if (st.random_keep >= 0) {
+        uint32_t keep = 0;
+        for (uint32_t bb = cand; bb; bb &= bb - 1) {
+            const int k = __ffs(bb) - 1, t = t0 + k, i = t / cols, j = t - i * cols;
+            const uint8_t r = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)i << 32) | (uint32_t)j)) & 0xff);
+            if (r <= (uint8_t)st.random_keep) keep |= 1u << k;
+        }
+        cand = keep;
+    }
+    return cand;
+}
 // 16 consecutive pixels per thread (one 16-byte load and store when the planes allow it).
 __global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uint8_t* __restrict__ mask_out) {
     const int pair = blockIdx.y;
@@ -842,7 +862,7 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
 constexpr int SCAN_U = 4;  // 16-pixel groups per thread of the scan kernel (64 consecutive pixels)
 __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
                                                                 int from_stamps, PixelPlanes pp, int cap_n) {
-    // 64 consecutive pixels per thread (a wavefront that does less is bound by its own launch); the workgroup's usable pixels get ONE
+    // four 16-pixel groups per thread (a wavefront that does less is bound by its own launch); the workgroup's usable pixels get ONE
     // reservation in the pair's list (a prefix sum over the workgroup, one global atomic); the 16 depths under a group with a pick come
     // in one round trip.
     __shared__ int s_wave[4], s_base;
@@ -853,7 +873,8 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     const uint16_t* dp = depth + (size_t)pair * S0;
     uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
     const bool vec = cols0 % 16 == 0 && S0 % 16 == 0;
-    const int tb = (blockIdx.x * 256 + tid) * (16 * SCAN_U);
+    // group u of a thread: pixels [t0(u), t0(u) + 16), consecutive lanes on consecutive groups (every load / store instruction is contiguous)
+#define SCAN_T0(u) (((blockIdx.x * SCAN_U + (u)) * 256 + tid) * 16)
     DsoState st{};
     if (from_stamps) st = ws.state[pair];
     uint32_t usable[SCAN_U];
@@ -861,18 +882,20 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     if (vec) {
         uint4 pk[SCAN_U];
 #pragma unroll
-        for (int u = 0; u < SCAN_U; ++u) pk[u] = (tb + 16 * u < S0) ? *reinterpret_cast<const uint4*>(src + tb + 16 * u) : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < SCAN_U; ++u) pk[u] = (SCAN_T0(u) < S0) ? *reinterpret_cast<const uint4*>(src + SCAN_T0(u)) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < SCAN_U; ++u) {
-            const int t0 = tb + 16 * u;
+            const int t0 = SCAN_T0(u);
             const uint4 p4 = pk[u];
             uint32_t bits = 0;
             if ((p4.x | p4.y | p4.z | p4.w) != 0) {
                 const uint32_t w[4] = {p4.x, p4.y, p4.z, p4.w};
+                if (from_stamps) {
+                    bits = dso_final_bits16(st, w, t0, cols0);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int bq = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
-                    if (bq && (!from_stamps || dso_final_mask(st, bq, t0 + k, cols0))) bits |= 1u << k;
+                    for (int k = 0; k < 16; ++k)
+                        if ((w[k >> 2] >> (8 * (k & 3))) & 0xff) bits |= 1u << k;
                 }
             }
             if (from_stamps && t0 < S0) {
@@ -895,7 +918,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     } else {
 #pragma unroll
         for (int u = 0; u < SCAN_U; ++u) {
-            const int t0 = tb + 16 * u;
+            const int t0 = SCAN_T0(u);
             uint32_t us = 0;
             for (int k = 0; k < 16 && t0 + k < S0; ++k) {
                 const int bq = src[t0 + k];
@@ -928,7 +951,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
 #pragma unroll
     for (int u = 0; u < SCAN_U; ++u) {
         if (usable[u] == 0) continue;
-        const int t0 = tb + 16 * u, y0 = t0 / cols0, x0 = t0 - y0 * cols0;
+        const int t0 = SCAN_T0(u), y0 = t0 / cols0, x0 = t0 - y0 * cols0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (!((usable[u] >> k) & 1u)) continue;
@@ -942,6 +965,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
         }
     }
 }
+#undef SCAN_T0
 __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                     const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
                                                                     int from_stamps, PixelPlanes pp, Records rec, int cap_n) {
