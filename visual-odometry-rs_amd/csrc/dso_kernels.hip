@@ -680,7 +680,7 @@ __device__ __forceinline__ uint32_t morton_compact(uint32_t k) {
     k = (k | (k >> 8)) & 0x0000FFFFu;
     return k;
 }
-constexpr int SPARSE_LDS_N = 4096;  // entries of the LDS form: sort words 32 KB + (key, inverse depth, weight) 48 KB: two workgroups per CU
+constexpr int SPARSE_LDS_N = 4096;  // entries of the LDS form: 48 KB (sort words, then key / inverse depth / weight in their place): three workgroups per CU
 // Exclusive position of a flagged thread among the flagged threads of the workgroup (1024 threads), plus their number.
 // Two barriers; `s_wave` is workgroup scratch.
 __device__ __forceinline__ int block_rank(bool flag, int* s_wave, int* total) {
@@ -781,11 +781,27 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
     // at a barrier, then writes (the outputs of a level land at or below inputs already consumed).
     float* dd = reinterpret_cast<float*>(key + cap_set);
     float* vv = reinterpret_cast<float*>(key + 2 * cap_set);
-    for (int i = tid; i < n0; i += 1024) {
-        const uint64_t c = a[i];
-        key[i] = (uint32_t)(c >> 16);
-        dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);  // from_depth, inverse_depth.rs:24-29
-        vv[i] = g.idepth_variance;
+    if (copy_in) {  // LDS form: the arrays take the place of the sorted words (n0 <= 4096: four words per thread through registers)
+        uint64_t c[SPARSE_LDS_N / 1024];
+#pragma unroll
+        for (int q = 0; q < SPARSE_LDS_N / 1024; ++q) c[q] = tid + 1024 * q < n0 ? a[tid + 1024 * q] : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPARSE_LDS_N / 1024; ++q) {
+            const int i = tid + 1024 * q;
+            if (i < n0) {
+                key[i] = (uint32_t)(c[q] >> 16);
+                dd[i] = g.depth_scale / (float)(uint32_t)(c[q] & 0xffffu);  // from_depth, inverse_depth.rs:24-29
+                vv[i] = g.idepth_variance;
+            }
+        }
+    } else {
+        for (int i = tid; i < n0; i += 1024) {
+            const uint64_t c = a[i];
+            key[i] = (uint32_t)(c >> 16);
+            dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);
+            vv[i] = g.idepth_variance;
+        }
     }
     __syncthreads();
     int n = n0;
@@ -969,8 +985,8 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
 __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                     const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
                                                                     int from_stamps, PixelPlanes pp, Records rec, int cap_n) {
-    __shared__ uint64_t lds_sort[SPARSE_LDS_N];
-    __shared__ uint32_t lds_set[3 * SPARSE_LDS_N];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_set[3 * SPARSE_LDS_N];  // 48 KB: the sort words first (32 KB), then the three arrays in their place
+    uint64_t* lds_sort = reinterpret_cast<uint64_t*>(lds_set);
     __shared__ int s_n, s_wave[16], s_out[VORS_MAX_LEVELS];
     __shared__ uint32_t s_prev;
     const int pair = blockIdx.x, tid = threadIdx.x;
