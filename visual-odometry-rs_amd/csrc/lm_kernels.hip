@@ -1170,6 +1170,11 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
     float acc[NACC];
     Iso cur_model = *model;
     int cur = 0;
+#ifndef VORS_TWO_PHASE_UNITS
+#define VORS_TWO_PHASE_UNITS 2048
+#endif
+    constexpr bool TWO_PHASE = Src::FUSED && Src::G == 4;  // dense quad levels of the fused arithmetic
+    const bool two_phase = TWO_PHASE && n_slots >= VORS_TWO_PHASE_UNITS;
     float cur_energy, lm_coef = 0.1f;
     int nb_iter = 0;
     Iso cand = cur_model;
@@ -1202,10 +1207,35 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
             cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
         }
         have_cand = false;
+        const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
+        if constexpr (TWO_PHASE) {
+            if (two_phase) {  // (uniform) large dense level: a candidate's energy alone first, like eval_energy (lm_optimizer.rs:68-87) ...
+                eval_accumulate<BLOCK, HUBER, false, Src, true>(src, n_slots, c, cand, acc, nullptr);
+                float e_sum = acc[0], e_cnt = acc[1];
+                block_sum2<BLOCK>(e_sum, e_cnt, s);
+                const float energy = uniform_f(e_sum / e_cnt);
+                if (energy > cur_energy) {
+                    if (too_many_iterations) break;
+                    lm_coef *= 10.0f;
+                    continue;
+                }
+                const float d_energy = cur_energy - energy;
+                n_full += 1;
+                cur_energy = energy;
+                cur_model = cand;
+                if (too_many_iterations) break;
+                lm_coef = 0.1f * lm_coef;
+                if (!(d_energy > 1.0f)) break;
+                // ... and its g and H (compute_eval_data, :90-107) only when the level goes on from it
+                eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cand, acc, nullptr);
+                block_reduce<BLOCK>(acc, s, 1 - cur);
+                cur = 1 - cur;
+                continue;
+            }
+        }
         eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cand, acc, nullptr);  // eval(): lm_optimizer.rs:140-149
         block_reduce<BLOCK>(acc, s, 1 - cur);
         const float energy = uniform_f(s.sums[1 - cur][0] / s.sums[1 - cur][1]);
-        const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
         if (energy > cur_energy) {                      // Err(energy)
             if (too_many_iterations) break;
             lm_coef *= 10.0f;
