@@ -134,7 +134,9 @@ typedef struct vors_batch vors_batch;
  *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before per-pair workgroups finish the stragglers (default 26 / 16 / 10 by batch size)
  *   VORS_LM_CHUNKS=n             partial-sum chunks per pair of a level-0 evaluation (default by batch size)
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
- *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical) */
+ *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical)
+ *   VORS_DSO_PLANES=1            DSO mode: keyframe records through per-level inverse-depth planes instead of the sorted pick list
+ *                                (same candidates and values; the lists then come out in raster instead of Morton order) */
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
 /* Same on an explicit HIP device (vors_batch_create = the calling thread's current device). The handle remembers its device: every
  * entry point switches to it for the call and restores the caller's current device; a hip_stream of another device is rejected with
