@@ -1,5 +1,5 @@
-"""One-off robustness sweep of the DSO keyframe path (development aid; run through gpurun): random shapes / level counts, candidate
-counts and statuses against the oracle, poses within 1e-4.   usage: python tools/dso_shape_sweep.py [n_cases] [seed]"""
+"""One-off robustness sweep (development aid; run through gpurun): random shapes / level counts, candidate counts and statuses against
+the oracle, poses within 1e-4.   usage: python tools/shape_sweep.py [n_cases] [seed] [mode: 0 coarse-to-fine, 1 dense, 2 DSO (default)]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
@@ -8,6 +8,7 @@ import vors_amd as V
 from oracle import oracle as O
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 bad = 0
 for i in range(n_cases):
     rows, cols = int(rng.integers(24, 300)), int(rng.integers(32, 400))
@@ -15,10 +16,10 @@ for i in range(n_cases):
     L = int(rng.integers(1, 7))
     while (min(rows, cols) >> (L - 1)) < 2: L -= 1
     intr = O.scaled_intrinsics(rows, cols)
-    kg, kd, cg, cd, gt = O.synth_batch(2, rows, cols, seed0=(1 << 63) | (0x5EEDAA00 + 8 * i), intr=intr)
-    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=2), kg, kd, cg)
+    kg, kd, cg, cd, gt = O.synth_batch(2, rows, cols, seed0=((1 << 63) if MODE == 2 else 0) | (0x5EEDAA00 + 8 * i), intr=intr)
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=MODE), kg, kd, cg)
     for arith in (0, 1):
-        cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=2, arithmetic=arith)
+        cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=MODE, arithmetic=arith)
         b = V.Batch(cfg, 2, rows, cols)
         t = [torch.from_numpy(np.ascontiguousarray(kg)).cuda(), torch.from_numpy(np.ascontiguousarray(kd).view(np.int16)).cuda(), torch.from_numpy(np.ascontiguousarray(cg)).cuda()]
         poses = torch.zeros((2, 7), device="cuda"); status = torch.zeros(2, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(2)
@@ -29,5 +30,7 @@ for i in range(n_cases):
         err = np.abs(poses.cpu().numpy() - ref["poses"])[good].max(initial=0)
         if not ok or err > 1e-4:
             bad += 1
+            rv = O.track_pairs(O.make_config(L, intr, candidates_mode=MODE), kg, kd, cg, variant="acc64")  # the oracle's own sensitivity build
+            print(f"   (oracle[acc64] vs oracle on these pairs: {np.abs(rv['poses'] - ref['poses'])[good].max(initial=0):.2e}; iterations oracle {ref['nb_iter'].tolist()} gpu {st['nb_iter'][:, :L].tolist()})")
             print(f"MISMATCH case {i}: {cols}x{rows} L{L} arith {arith}: status {status.cpu().numpy()} vs {ref['status']}, points {st['n_points'][:, :L].tolist()} vs {ref['n_points'].tolist()}, pose err {err:.2e}")
-print(f"{n_cases} shapes x 2 arithmetics: {bad} mismatches")
+print(f"mode {MODE}: {n_cases} shapes x 2 arithmetics: {bad} mismatches")
