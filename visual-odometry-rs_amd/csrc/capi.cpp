@@ -44,6 +44,10 @@ static vors_status require_device() {
 // ---------------------------------------------------------------------------------------------------------------
 // geometry
 // ---------------------------------------------------------------------------------------------------------------
+// FUSED arithmetic: levels of at most this many points are evaluated in the EXACT arithmetic (engine.h Geom::fused_exact_points).
+#ifndef VORS_FUSED_EXACT_POINTS_DEFAULT
+#define VORS_FUSED_EXACT_POINTS_DEFAULT 2500
+#endif
 static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* g) {
     if (!cfg) return fail(VORS_ERR_INVALID_ARGUMENT, "cfg is NULL");
     if (cfg->nb_levels < 1 || cfg->nb_levels > VORS_MAX_LEVELS)
@@ -66,6 +70,8 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     g->depth_scale = cfg->depth_scale;
     g->idepth_variance = cfg->idepth_variance;
     g->huber_delta = cfg->huber_delta;
+    g->fused_exact_points = getenv("VORS_FUSED_EXACT_POINTS") ? atoi(getenv("VORS_FUSED_EXACT_POINTS")) : VORS_FUSED_EXACT_POINTS_DEFAULT;
+    g->fused_exact_step = getenv("VORS_FUSED_EXACT_STEP") ? atoi(getenv("VORS_FUSED_EXACT_STEP")) : 0;
     g->S0 = rows * cols;
     int r = rows, c = cols;
     Intr k{cfg->cu, cfg->cv, cfg->fu, cfg->fv, cfg->skew};
@@ -128,6 +134,7 @@ struct vors_batch {
     int max_pairs = 0;
     int device = 0;          // HIP device the workspaces live on (vors_batch_create_on); every entry point switches to it
     int prepared_pairs = 0;  // n_pairs of the last prepare_keyframes: track_current may not ask for more
+    int current_pairs = 0;   // n_pairs of the last track_current: the current-frame pyramid slots that hold an image
     uint8_t* kf_upper = nullptr;
     uint8_t* cur_upper = nullptr;
     const uint8_t* kf_level0 = nullptr;   // caller's buffer of the last prepare_keyframes
@@ -389,6 +396,8 @@ vors_status vors_batch_workspace_bytes(const vors_batch* b, uint64_t* bytes) {
 vors_status vors_batch_enable_kernel_timing(vors_batch* b, int ring) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
     if (ring < 0 || ring > 4096) return fail(VORS_ERR_INVALID_ARGUMENT, "ring must be in [0, 4096]");
+    DeviceGuard guard(b->device);  // events belong to the device that is current when they are created: the handle's, not the caller's
+    if (!guard.ok) return fail(VORS_ERR_HIP, "hipSetDevice failed");
     b->ring = 0;  // stays off if an event cannot be created below
     for (int st = 0; st < 4; ++st) {
         for (auto e : b->ev0[st])
@@ -477,6 +486,7 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
         return fail(VORS_ERR_INVALID_ARGUMENT, "track_current: n_pairs (" + std::to_string(n_pairs) + ") exceeds the " +
                                                    std::to_string(b->prepared_pairs) + " keyframes prepared on this handle");
     b->cur_level0 = d_cur_gray;
+    b->current_pairs = n_pairs;
     Pyramid cur{d_cur_gray, b->cur_upper};
     STAGE_BEGIN(b, 2, s);
     launch_pyramid(b->g, cur, n_pairs, s);
@@ -510,6 +520,7 @@ vors_status vors_batch_track_pairs(vors_batch* b, int n_pairs, const uint8_t* d_
 
 vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int capacity, int* n_out) {
     if (!b || !n_out || stage < 0 || stage > 3 || (capacity > 0 && !ms_out)) return fail(VORS_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(b->device);
     const int n = (int)std::min<long>(b->count[stage], b->ring);
     *n_out = n;
     for (int k = 0; k < n && k < capacity; ++k) {
@@ -523,6 +534,7 @@ vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int
 
 vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms) {
     if (!b) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    DeviceGuard guard(b->device);
     float v[4] = {-1.f, -1.f, -1.f, -1.f};
     for (int st = 0; st < 4; ++st)
         if (b->ring > 0 && b->count[st] > 0) {
@@ -617,7 +629,8 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
 
 vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const float model7[7], int arithmetic, float sums29[29]) {
     if (!b || !model7 || !sums29) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (pair < 0 || pair >= b->prepared_pairs || level < 0 || level >= b->g.L) return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range");
+    if (pair < 0 || pair >= std::min(b->prepared_pairs, b->current_pairs) || level < 0 || level >= b->g.L)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range (pair must be < the n_pairs of the last prepare_keyframes AND track_current)");
     if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
     if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED) return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
     DeviceGuard guard(b->device);

@@ -8,6 +8,13 @@ namespace vors {
 
 #define VORS_INVALID_XY 0xFFFFFFFFu
 
+// Pair addressed by index k of a kernel's pair dimension: k itself, or — masked launch (Geom::sel_list) — the k-th selected pair,
+// -1 beyond the selection (the workgroup has nothing to do). Workgroup-uniform.
+__device__ __forceinline__ int select_pair(const Geom& g, int k) {
+    if (!g.sel_list) return k;
+    return k < *g.sel_count ? g.sel_list[k] : -1;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // image helpers
 // ------------------------------------------------------------------------------------------------------------

@@ -44,7 +44,8 @@ __device__ __forceinline__ void dso_hist_add(int* hist, int v, bool active) {
 }
 __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws, bool wide) {
     __shared__ int s_hist[4][256];
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int region = blockIdx.x * 4 + wave;
     if (region >= ws.n_regions) return;
@@ -150,7 +151,8 @@ __device__ __forceinline__ void dso_for_each(int n, F f) {
 __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
     __shared__ DsoState st;
     __shared__ int s_count;
-    const int pair = blockIdx.x;
+    const int pair = select_pair(g, blockIdx.x);
+    if (pair < 0) return;
     const int rows = g.lv[0].rows, cols = g.lv[0].cols;
     const int rr = (rows + DSO_REGION - 1) / DSO_REGION, rc = (cols + DSO_REGION - 1) / DSO_REGION;
     const uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
@@ -321,7 +323,8 @@ __device__ __forceinline__ uint32_t dso_final_bits16(const DsoState& st, const u
 }
 // 16 consecutive pixels per thread (one 16-byte load and store when the planes allow it).
 __global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uint8_t* __restrict__ mask_out) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (t0 >= g.S0) return;
     const DsoState st = ws.state[pair];
@@ -363,7 +366,8 @@ __device__ __forceinline__ float level0_idepth(const Geom& g, const uint16_t* __
 // Level l >= 1 of the inverse-depth pyramid from level l - 1 (strategy_dso_mean, inverse_depth.rs:81-98; children in order a,b,c,d).
 __global__ __launch_bounds__(256) void mask_idepth_halve_kernel(Geom g, int l, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                                  PixelPlanes pp) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[l].rows, cols = g.lv[l].cols;
     if (t >= rows * cols) return;
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(256) void mask_idepth_halve_kernel(Geom g, int l, c
 template <bool FROM_DSO>
 __global__ __launch_bounds__(256) void mask_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask,
                                                                        PixelPlanes pp, DsoWs ws) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int rows = g.lv[1].rows, cols = g.lv[1].cols, fc = g.lv[0].cols;
     const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (t0 >= rows * cols) return;
@@ -556,7 +561,9 @@ __device__ __forceinline__ unsigned usable16(const Geom& g, const PixelPlanes& p
 __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                              PixelPlanes pp, int first_chunk) {
     __shared__ int s_wave[4];
-    const int pair = blockIdx.y, c = first_chunk + blockIdx.x;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int c = first_chunk + blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int n = g.lv[l].rows * g.lv[l].cols;
     const int t0 = (c - pp.chunk_off[l]) * VORS_CHUNK_PX + threadIdx.x * 16;
@@ -572,7 +579,9 @@ __global__ __launch_bounds__(256) void generic_count_kernel(Geom g, const uint16
 __global__ __launch_bounds__(256) void generic_compact_kernel(Geom g, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                                PixelPlanes pp, Records rec) {
     __shared__ int s_before[4], s_wave[4];
-    const int pair = blockIdx.y, c = blockIdx.x;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int c = blockIdx.x;
     const int l = chunk_level(pp, g.L, c);
     const int rows = g.lv[l].rows, cols = g.lv[l].cols, n = rows * cols, cap = g.lv[l].n_slots;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -616,7 +625,9 @@ __global__ __launch_bounds__(256) void generic_compact_kernel(Geom g, const uint
 __global__ __launch_bounds__(256) void generic_build_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                      const uint16_t* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                                      PixelPlanes pp, Records rec) {
-    const int pair = blockIdx.y, l = blockIdx.x / GENERIC_BUILD_WGS, w = blockIdx.x - l * GENERIC_BUILD_WGS;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int l = blockIdx.x / GENERIC_BUILD_WGS, w = blockIdx.x - l * GENERIC_BUILD_WGS;
     const int n = rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l], cols = g.lv[l].cols;
     const uint8_t* img = level_ptr(g, kf0, kfu, pair, l);
     const size_t slot0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
@@ -637,7 +648,7 @@ static void keyframe_from_mask(const Geom& g, Pyramid kf, const uint16_t* depth,
     for (int l = 1; l < g.L; ++l) {
         const int n = g.lv[l].rows * g.lv[l].cols;
         if (l == 1 && dso) {  // (the caller checked the shape: cols % 16 == 0, rows even)
-            (void)hipMemsetAsync(pp.counts, 0, (size_t)n_pairs * pp.chunks_total * sizeof(int), s);
+            launch_zero_ints(g, pp.counts, pp.chunks_total, n_pairs, s);
             hipLaunchKernelGGL(mask_idepth_level1_wide_kernel<true>, dim3((n / 8 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, mask, pp, *dso);
             first_chunk = pp.chunk_off[1];  // the level-0 chunks have been counted
         } else if (l == 1 && g.lv[0].cols % 16 == 0) {
@@ -882,13 +893,16 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     // reservation in the pair's list (a prefix sum over the workgroup, one global atomic); the 16 depths under a group with a pick come
     // in one round trip.
     __shared__ int s_wave[4], s_base;
-    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S0 = g.S0, cols0 = g.lv[0].cols;
     const uint8_t* src = (from_stamps ? ws.picked : mask) + (size_t)pair * S0;
     uint8_t* mout = mask + (size_t)pair * S0;
     const uint16_t* dp = depth + (size_t)pair * S0;
     uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
-    const bool vec = cols0 % 16 == 0 && S0 % 16 == 0;
+    // 16-byte loads need 16-byte aligned planes: the mask / stamp planes are the handle's own (hipMalloc), the depth map is the caller's
+    const bool vec = cols0 % 16 == 0 && S0 % 16 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0;
     // group u of a thread: pixels [t0(u), t0(u) + 16), consecutive lanes on consecutive groups (every load / store instruction is contiguous)
 #define SCAN_T0(u) (((blockIdx.x * SCAN_U + (u)) * 256 + tid) * 16)
     DsoState st{};
@@ -989,7 +1003,9 @@ __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const
     uint64_t* lds_sort = reinterpret_cast<uint64_t*>(lds_set);
     __shared__ int s_n, s_wave[16], s_out[VORS_MAX_LEVELS];
     __shared__ uint32_t s_prev;
-    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int pair = select_pair(g, blockIdx.x);
+    if (pair < 0) return;
+    const int tid = threadIdx.x;
     const int S0 = g.S0, rows0 = g.lv[0].rows, cols0 = g.lv[0].cols;
     uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
     uint32_t* gset = reinterpret_cast<uint32_t*>(pp.iz + (size_t)pair * pp.stride);
@@ -1060,7 +1076,7 @@ void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs
     while (2 * cap_n <= pp.stride / 3) cap_n *= 2;
     static const bool force_planes = getenv("VORS_DSO_PLANES") && atoi(getenv("VORS_DSO_PLANES")) != 0;
     if (!force_planes && cap_n >= (1 << (g.L - 1)) * g.lv[0].cols && g.lv[0].cols < 65536 && g.lv[0].rows < 65536) {  // a band alone fits
-        (void)hipMemsetAsync(pp.counts, 0, (size_t)n_pairs * pp.chunks_total * sizeof(int), s);
+        launch_zero_ints(g, pp.counts, pp.chunks_total, n_pairs, s);
         hipLaunchKernelGGL(mask_sparse_scan_kernel, dim3((g.S0 + 256 * 16 * SCAN_U - 1) / (256 * 16 * SCAN_U), n_pairs), dim3(256), 0, s, g, depth, mask, ws, 1, pp, cap_n);
         hipLaunchKernelGGL(mask_sparse_records_kernel, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, mask, ws, 1, pp, rec, cap_n);
         return;

@@ -34,7 +34,14 @@ struct Geom {
     int slots_total;    // record slots per pair (all levels)
     int root_rows, root_cols;  // shape of the coarsest level (= roots of the selection quad-trees)
     int fast_idepth;    // scale / depth through idepth_of<true> (kernels.hip): proven bit-identical to the division for all 65535 depths
+    // FUSED arithmetic: a level of at most this many points (dense: pixels of the level; sparse modes: candidates of the pair at the level)
+    // is evaluated in the EXACT arithmetic (lm_kernels.hip lm_track_kernel); fused_exact_step != 0 also takes its step() with lm_step
+    int fused_exact_points, fused_exact_step;
     int wide_loads_ok;  // set per launch: the caller's buffers are 16-byte aligned, so the dense quad source may use wide loads
+    // Masked launches of the keyframe stage (vors_trackers: per-sequence keyframe promotion on the device). When sel_list is set, index k
+    // of a kernel's pair dimension addresses pair sel_list[k] for k < *sel_count and nothing beyond (device_common.h select_pair).
+    const int* sel_list;
+    const int* sel_count;
     LevelGeom lv[VORS_MAX_LEVELS];
 };
 
@@ -152,6 +159,7 @@ struct Pyramid {
 void launch_transpose_u8(const uint8_t* src_colmajor, uint8_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_transpose_u16(const uint16_t* src_colmajor, uint16_t* dst_rowmajor, int rows, int cols, int n, hipStream_t s);
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
+void launch_zero_ints(const Geom& g, int* base, int stride, int n_pairs, hipStream_t s);  // per-pair counters -> 0 (honours Geom::sel_list)
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
 void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions);  // coarse-to-fine mode: roots per wavefront region, regions per pair
 void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
@@ -192,5 +200,13 @@ void launch_build_depth_lut(float depth_scale, float2* lut, hipStream_t s);
 void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const double cam5[5], double motion_scale,
                         int invalid_percent, uint8_t* kf_gray, uint16_t* kf_depth, uint8_t* cur_gray, uint16_t* cur_depth,
                         float* gt_models7, hipStream_t s);
+
+// Sequence tooling + the device side of vors_trackers_* (kernels.hip).
+void launch_synth_frames(const void* d_frames /* {u64 seed, u64 salt, f64 xi[6]} x n */, int n_frames, int rows, int cols, const double cam5[5],
+                         int invalid_percent, uint8_t* gray, uint16_t* depth, hipStream_t s);
+void launch_trackers_advance(int n_seq, int frame_index, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
+                             float* kf_poses7, int32_t* kf_frame, int* promo_list, int* promo_count, hipStream_t s);
+void launch_promote_copy(const Geom& g, const void* src, size_t src_stride, void* dst, size_t dst_stride, size_t bytes, int n_pairs,
+                         hipStream_t s);
 
 }  // namespace vors

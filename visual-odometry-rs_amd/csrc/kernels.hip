@@ -151,7 +151,8 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     float* s_d = reinterpret_cast<float*>(s_gr + KF_WAVES * KF_R * NODES);
     float* s_v = s_d + KF_WAVES * KF_R * NODES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int n_roots = g.root_rows * g.root_cols;
     const int root0 = (blockIdx.x * KF_WAVES + wave) * KF_R;  // first root of this wavefront
     const int L = g.L;
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
 __global__ __launch_bounds__(256) void compact_regions_kernel(Geom g, Records rec) {
     __shared__ int s_cnt[256], s_pre[256], s_wave[4];
     __shared__ int s_base;
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // all levels of a pair in one workgroup, finest (largest) first: a sixth of the workgroups of a (level, pair) grid, whose small
     // levels were nothing but dispatch (24,576 workgroups at 4096 pairs: 0.26 ms)
@@ -425,7 +427,8 @@ __device__ __forceinline__ void count_add(int* counter, int n) {
 // threads of the last level-1 row / column) and of level 1.
 template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[1].rows, cols = g.lv[1].cols;
     int n0 = 0, n1 = 0;
@@ -453,7 +456,8 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_kernel(Geom g, const 
 // 16-byte stores.
 template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int rows = g.lv[1].rows, cols = g.lv[1].cols;
     int n0 = 0, n1 = 0;
@@ -490,7 +494,8 @@ __global__ __launch_bounds__(256) void dense_idepth_level1_wide_kernel(Geom g, c
 template <bool FAST>
 __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
     // TWO horizontally adjacent level-2 pixels per thread: 16-byte loads of the four depth rows, 16-byte stores of the two level-1 rows
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const int rows2 = g.lv[2].rows, cols2 = g.lv[2].cols;  // cols2 is a multiple of 4 here
     int n0 = 0, n1 = 0, n2 = 0;
@@ -538,7 +543,8 @@ __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 2, n2);
 }
 __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, Records rec) {
-    const int pair = blockIdx.y;
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = g.lv[l].rows, cols = g.lv[l].cols;
     int n = 0;
@@ -605,6 +611,17 @@ void launch_dense_materialize(const Geom& g, int l, int pair, Pyramid kf, const 
                        depth, rec, out);
 }
 
+// Zero `stride` ints per pair of a per-pair counter array — all n_pairs pairs, or (masked launch, Geom::sel_list) the selected ones.
+__global__ __launch_bounds__(64) void zero_ints_kernel(Geom g, int* __restrict__ base, int stride) {
+    const int pair = select_pair(g, blockIdx.x);
+    if (pair < 0) return;
+    for (int i = threadIdx.x; i < stride; i += 64) base[(size_t)pair * stride + i] = 0;
+}
+void launch_zero_ints(const Geom& g, int* base, int stride, int n_pairs, hipStream_t s) {
+    if (!g.sel_list) (void)hipMemsetAsync(base, 0, (size_t)n_pairs * stride * sizeof(int), s);
+    else hipLaunchKernelGGL(zero_ints_kernel, dim3(n_pairs), dim3(64), 0, s, g, base, stride);
+}
+
 // Region geometry of the coarse-to-fine keyframe kernel (read by capi.cpp when it sizes the handle): roots per wavefront, and
 // wavefront regions per pair.
 static int keyframe_roots_per_wave(const Geom& g) {
@@ -619,9 +636,8 @@ void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions) {
     *n_regions = ((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r)) * KF_WAVES;
 }
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
-    const int n_roots = g.root_rows * g.root_cols;
     if (g.mode == VORS_CANDIDATES_DENSE) {
-        (void)hipMemsetAsync(rec.n_used, 0, (size_t)n_pairs * VORS_MAX_LEVELS * sizeof(int), s);
+        launch_zero_ints(g, rec.n_used, VORS_MAX_LEVELS, n_pairs, s);
         int next = 2;
         if (g.L >= 2) {
             // (slots_total and slot_off are multiples of 4, so the vector stores of the wide kernels are aligned)
@@ -641,9 +657,9 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         for (int l = next; l < g.L; ++l)
             hipLaunchKernelGGL(dense_idepth_halve_kernel, dim3((g.lv[l].n_slots + 255) / 256, n_pairs), dim3(256), 0, s, g, l, rec);
     } else {
-        const int r = keyframe_roots_per_wave(g);
-        dim3 grid((n_roots + KF_WAVES * r - 1) / (KF_WAVES * r), n_pairs);
-        if (rec.kf_r != r || rec.n_regions != (int)grid.x * KF_WAVES) return;  // the handle was sized for another region geometry (capi.cpp)
+        // the region geometry the handle was sized for (keyframe_region_geometry at create(), capi.cpp) is the single source of truth
+        const int r = rec.kf_r;
+        dim3 grid(rec.n_regions / KF_WAVES, n_pairs);
         const size_t lds = (size_t)KF_WAVES * r * (1 << g.L) * 16;
         if (r == 8) hipLaunchKernelGGL(keyframe_sparse_kernel<8>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
@@ -720,6 +736,103 @@ void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const d
     dim3 grid((rows * cols + 255) / 256, n_pairs);
     hipLaunchKernelGGL(synth_pairs_kernel, grid, dim3(256), 0, s, seed0, rows, cols, cam, motion_scale, invalid_percent, kf_gray,
                        kf_depth, cur_gray, cur_depth, gt_models7);
+}
+
+// Frames of the same scene family at explicit twists (sequence tooling): frame f is rendered with seed[f], salt[f] at exp(xi[f]).
+struct SynthFrame {
+    uint64_t seed, salt;
+    double xi[6];
+};
+__global__ void synth_frames_kernel(const SynthFrame* __restrict__ frames, int rows, int cols, vors_synth::CameraD cam, int invalid_percent,
+                                    uint8_t* __restrict__ gray, uint16_t* __restrict__ depth) {
+    const int f = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const SynthFrame fr = frames[f];
+    const vors_synth::RigidD m = vors_synth::se3_exp_d(fr.xi);
+    const int y = t / cols, x = t - y * cols;
+    const size_t o = (size_t)f * rows * cols + t;
+    uint8_t gq;
+    uint16_t dq;
+    vors_synth::render_pixel(fr.seed, fr.salt, cam, m, x, y, invalid_percent, &gq, &dq);
+    gray[o] = gq;
+    depth[o] = dq;
+}
+void launch_synth_frames(const void* d_frames, int n_frames, int rows, int cols, const double cam5[5], int invalid_percent, uint8_t* gray,
+                         uint16_t* depth, hipStream_t s) {
+    vors_synth::CameraD cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    dim3 grid((rows * cols + 255) / 256, n_frames);
+    hipLaunchKernelGGL(synth_frames_kernel, grid, dim3(256), 0, s, static_cast<const SynthFrame*>(d_frames), rows, cols, cam, invalid_percent, gray,
+                       depth);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// N sequences in lock-step (vors_trackers_*): the tracker state machine of inverse_compositional.rs:203-239 on the device.
+// ------------------------------------------------------------------------------------------------------------
+// After the LM stage of a frame: current_frame_pose <- the tracked pose (the LM kernel already wrote the previous pose for a sequence
+// whose optimizer failed, :206-208); a sequence whose optical flow reached the threshold (:224) takes the current frame as its keyframe:
+// keyframe_pose <- current_frame_pose (:238), and it is appended to the promotion list that the masked keyframe launches read.
+// One workgroup; the list comes out in sequence order (wave ballots + a running base), so every launch that follows is deterministic.
+__global__ __launch_bounds__(256) void trackers_advance_kernel(int n_seq, int frame_index, const float* __restrict__ out_poses7,
+                                                               const vors_pair_stats* __restrict__ stats, float* __restrict__ cur_poses7,
+                                                               float* __restrict__ kf_poses7, int32_t* __restrict__ kf_frame,
+                                                               int* __restrict__ promo_list, int* __restrict__ promo_count) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s0 = 0; s0 < n_seq; s0 += 256) {
+        const int s = s0 + (int)threadIdx.x;
+        bool promote = false;
+        if (s < n_seq) {
+            promote = stats[s].change_keyframe != 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const float v = out_poses7[7 * s + q];
+                cur_poses7[7 * s + q] = v;
+                if (promote) kf_poses7[7 * s + q] = v;
+            }
+            if (promote) kf_frame[s] = frame_index;
+        }
+        const unsigned long long m = __ballot(promote);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (promote) promo_list[before + __popcll(m & ((1ull << lane) - 1ull))] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *promo_count = s_base;
+}
+void launch_trackers_advance(int n_seq, int frame_index, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
+                             float* kf_poses7, int32_t* kf_frame, int* promo_list, int* promo_count, hipStream_t s) {
+    hipLaunchKernelGGL(trackers_advance_kernel, dim3(1), dim3(256), 0, s, n_seq, frame_index, out_poses7, stats, cur_poses7, kf_poses7, kf_frame,
+                       promo_list, promo_count);
+}
+// Dense mode keeps its keyframes (level 0, depth map, upper pyramid levels) in the handle: the promoted sequences copy theirs from the
+// current frame (the reference MOVES the current pyramid into the keyframe, inverse_compositional.rs:230-235). 16 bytes per thread.
+__global__ __launch_bounds__(256) void promote_copy_kernel(Geom g, const uint8_t* __restrict__ src, size_t src_stride, uint8_t* __restrict__ dst,
+                                                           size_t dst_stride, size_t bytes, int vec) {
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const uint8_t* sp = src + (size_t)pair * src_stride;
+    uint8_t* dp = dst + (size_t)pair * dst_stride;
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (t >= bytes) return;
+    if (vec && t + 16 <= bytes) {
+        *reinterpret_cast<uint4*>(dp + t) = *reinterpret_cast<const uint4*>(sp + t);
+    } else {
+        for (size_t k = t; k < bytes && k < t + 16; ++k) dp[k] = sp[k];
+    }
+}
+void launch_promote_copy(const Geom& g, const void* src, size_t src_stride, void* dst, size_t dst_stride, size_t bytes, int n_pairs,
+                         hipStream_t s) {
+    const int vec = (((uintptr_t)src | (uintptr_t)dst | src_stride | dst_stride) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(promote_copy_kernel, dim3((unsigned)((bytes + 4095) / 4096), n_pairs), dim3(256), 0, s, g, static_cast<const uint8_t*>(src),
+                       src_stride, static_cast<uint8_t*>(dst), dst_stride, bytes, vec);
 }
 
 }  // namespace vors

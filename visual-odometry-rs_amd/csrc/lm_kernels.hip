@@ -36,6 +36,24 @@ namespace vors {
 
 constexpr bool kFused = VORS_FUSED != 0;
 
+// Ablation knobs of the FUSED arithmetic (development builds only: tools/build_variant.sh; all 0 in the product). Each one puts ONE
+// ingredient of FUSED back to the reference's arithmetic so that tools/parity_ablate.py can attribute the out-of-tolerance tail.
+#ifndef VORS_ABL_EXACT_STEP
+#define VORS_ABL_EXACT_STEP 0     // step(): lm_step (IEEE sqrt / divisions) instead of lm_step_fast
+#endif
+#ifndef VORS_ABL_IEEE_IDEPTH
+#define VORS_ABL_IEEE_IDEPTH 0    // dense level 0: scale / depth as an IEEE division instead of scale * rcp(depth)
+#endif
+#ifndef VORS_ABL_WIDE_IDENTITY
+#define VORS_ABL_WIDE_IDENTITY 0  // near-identity window (EXACT fallback) 1e-4 / 1e-4 instead of 5e-6 / 1e-6
+#endif
+#ifndef VORS_ABL_IEEE_RCP
+#define VORS_ABL_IEEE_RCP 0       // warp: IEEE 1 / z' instead of v_rcp_f32
+#endif
+#ifndef VORS_ABL_EXACT_WARP
+#define VORS_ABL_EXACT_WARP 0     // warp: (u, v) from the reference's chain (back_project, Iso3 * p, project); the rest stays FUSED
+#endif
+
 
 #define NACC 29
 #define LM_MAX_WAVES 16
@@ -383,6 +401,8 @@ struct ImgCtx {
     float huber;
     double inv_fu_d, inv_fv_d;    // level constants of the fused arithmetic (engine.h LevelGeom), 0 = form them here
     float inv_fu, inv_fv, s_fuv;
+    bool force_exact = false;     // FUSED kernels: evaluate this level in the EXACT arithmetic (workgroup-uniform)
+    bool exact_step = false;      // FUSED kernels: step() with lm_step instead of lm_step_fast at this level
 };
 
 // warp (lm_optimizer.rs:213-219) + interpolate's inside test (lm_optimizer.rs:227-231): tap address or "outside".
@@ -526,7 +546,7 @@ __device__ __forceinline__ FusedCtx make_fused_ctx(const ImgCtx& c, const Iso& m
 // Workgroup-uniform: would this model move some pixel by less than ~1e-2 px?  (|rotation| <= 1e-5 rad, |t| <= 1e-6 m.)
 __device__ __forceinline__ bool model_near_identity(const Iso& m) {
     const float r = fmaxf(fmaxf(fabsf(m.q.i), fabsf(m.q.j)), fabsf(m.q.k)), t = fmaxf(fmaxf(fabsf(m.t.x), fabsf(m.t.y)), fabsf(m.t.z));
-    return __builtin_amdgcn_readfirstlane((r <= 5e-6f && t <= 1e-6f) ? 1 : 0) != 0;
+    return __builtin_amdgcn_readfirstlane((r <= (VORS_ABL_WIDE_IDENTITY ? 1e-4f : 5e-6f) && t <= (VORS_ABL_WIDE_IDENTITY ? 1e-4f : 1e-6f)) ? 1 : 0) != 0;
 }
 // The context of (level intrinsics, model) written to / read from the split state (LmSplitState::fctx): formed by ONE thread per
 // pair and round; the evaluation workgroups read it with scalar loads.
@@ -598,6 +618,9 @@ struct FUnit {
     uint32_t tmw;               // template grey levels, one byte per point
     float gu[G], gv[G];         // integer gradients as floats (zero on the level-0 border); not set for energy-only evaluations
     bool valid[G];
+#if VORS_ABL_EXACT_WARP
+    float px[G], py[G];         // pixel coordinates (ablation: the reference's warp chain)
+#endif
 };
 // What stage C (bilinear, residual, Jacobian, sums) needs of a unit whose taps are in flight.
 // What bounds this loop (round 2, per-kernel probes with tools/lm_variants.sh at 4096 pairs, level-0 rounds):
@@ -629,7 +652,7 @@ __device__ __forceinline__ float cvt_ubyte(W w) {  // float(byte BYTE of w): one
 }
 // Stage B: warp (see the header of this section) + inside test + tap requests.
 template <bool ENERGY_ONLY, int G>
-__device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st) {
+__device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st, const Iso& model) {
     // gfx950 issues v_fma / v_mul / v_add / shifts every ~2.6 cycles but conversions, compares, selects, v_floor and v_fract every ~4.4
     // and v_rcp every ~8.9 (tools/ubench/valu_ops): floor-to-integer in ONE conversion (v_cvt_flr_i32_f32), the fractional part in one
     // v_fract, and the window test as two unsigned integer compares instead of four float ones.
@@ -642,11 +665,18 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
 #pragma unroll
     for (int g = 0; g < G; ++g) hv[g] = fmaf(f.m1, p.iz[g], p.bv[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) rz[g] = __builtin_amdgcn_rcpf(hz[g]);
+    for (int g = 0; g < G; ++g) rz[g] = VORS_ABL_IEEE_RCP ? 1.0f / hz[g] : __builtin_amdgcn_rcpf(hz[g]);
 #pragma unroll
     for (int g = 0; g < G; ++g) u[g] = hu[g] * rz[g];
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = hv[g] * rz[g];
+#if VORS_ABL_EXACT_WARP
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const V3 P = back_project(c.k, p.px[g], p.py[g], 1.0f / p.iz[g]);
+        project_uv(c.k, iso_transform_point(model, P), &u[g], &v[g]);
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu[g]) : "v"(u[g]));  // (int)floor(u), saturating
 #pragma unroll
@@ -795,6 +825,9 @@ struct FusedPixSrc : DenseSrc<LEVEL0> {  // one pixel per unit, any width
         p.tmw = (uint32_t)r.tm;
         p.gu[0] = (float)r.gx;
         p.gv[0] = (float)r.gy;
+#if VORS_ABL_EXACT_WARP
+        p.px[0] = xf; p.py[0] = yf;
+#endif
     }
 };
 template <bool LEVEL0>
@@ -823,6 +856,10 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
         p.bv[0] = bv0; p.bv[1] = bv0 + f.h10; p.bv[2] = bv0 + f.h10_2; p.bv[3] = bv0 + f.h10_3;
         p.bz[0] = bz0; p.bz[1] = bz0 + f.h20; p.bz[2] = bz0 + f.h20_2; p.bz[3] = bz0 + f.h20_3;
         p.tmw = l.cw;
+#if VORS_ABL_EXACT_WARP
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p.px[j] = x0f + (float)j; p.py[j] = yf; }
+#endif
         const int rows = this->rows, cols = this->cols;
         if (LEVEL0) {
             float dzf[4], rd[4];
@@ -837,7 +874,8 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
 #pragma unroll
             for (int j = 0; j < 4; ++j)  // scale / depth (inverse_depth.rs:24-29) as scale * rcp(depth); an unknown depth (rcp = inf) is
                                          // clamped to a finite value (v_min is full rate, a select is not); `valid` masks the point
-                p.iz[j] = fminf(depth_scale * rd[j], 1e18f);  // (the exact table of the EXACT path as a gather here: +25-45 % on the round)
+                p.iz[j] = (VORS_ABL_IEEE_IDEPTH || VORS_ABL_EXACT_WARP) ? fminf(depth_scale / dzf[j], 1e18f)
+                                                                      : fminf(depth_scale * rd[j], 1e18f);  // (the exact table of the EXACT path as a gather here: +25-45 % on the round)
             if (!ENERGY_ONLY) {  // centred differences, truncating /2, zero on the 1-px border (gradient.rs:15-33): integer, exact
                 const int yin = (l.y > 0 && l.y < rows - 1) ? -1 : 0;
                 int tm[4];
@@ -906,6 +944,9 @@ struct FusedSlimSrc : SlimSrc {  // compact 12-byte candidate lists, two points 
             p.iz[g] = r.r[g].iz;  // always a known inverse depth: the lists hold candidates only
             p.gu[g] = (float)slim_gx(r.r[g].tg);
             p.gv[g] = (float)slim_gy(r.r[g].tg);
+#if VORS_ABL_EXACT_WARP
+            p.px[g] = xf[g]; p.py[g] = yf[g];
+#endif
         }
     }
 };
@@ -964,7 +1005,7 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
         // test (lm_optimizer.rs:227-231) the border rows / columns fall: 1-3 % of the points at the coarsest level, and with them the
         // first energy and the path of the whole LM loop. Only the reference's evaluation order reproduces that, so such an
         // evaluation runs in the exact arithmetic (a handful per pair, mostly at the coarsest level).
-        if (pre ? fused_ctx_exact(pre) : model_near_identity(model)) {
+        if (c.force_exact || (pre ? fused_ctx_exact(pre) : model_near_identity(model))) {
             eval_accumulate<BLOCK, HUBER, false, typename Src::Base, ENERGY_ONLY>(static_cast<const typename Src::Base&>(src), n_units, c, model, acc,
                                                                                nullptr, first);
             return;
@@ -978,7 +1019,7 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
             FUnit<Src::G> un;
             src.template funit<ENERGY_ONLY>(raw, f, un);
             FusedStage<Src::G> st;
-            fused_stage_b<ENERGY_ONLY>(un, c, f, st);
+            fused_stage_b<ENERGY_ONLY>(un, c, f, st, model);
             fused_stage_c<HUBER, ENERGY_ONLY>(c, jk, st, acc, cnt);
         }
         acc[1] = (float)cnt;
@@ -1062,6 +1103,9 @@ __device__ __forceinline__ void block_reduce(const float acc[NACC], LmShared& s,
     __syncthreads();
 }
 
+template <int BLOCK>
+__device__ __forceinline__ void block_sum2(float& a, float& b, LmShared& s);  // (defined after solve_level)
+
 // step(): lm_optimizer.rs:123-136, by ONE lane on the kept state's sums; result broadcast through LDS.
 // FUSED arithmetic: step() (lm_optimizer.rs:123-136) with the 6x6 Cholesky factor scaled by reciprocal square roots and the two
 // triangular solves by the stored reciprocals (6 v_rsq + multiplies instead of 6 IEEE square roots and 33 IEEE divisions, FMAs
@@ -1137,7 +1181,7 @@ __device__ __forceinline__ bool lm_step_fast(const float* h, const float* g, con
     return true;
 }
 template <bool FAST>
-__device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso& model, float lm_coef) {
+__device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso& model, float lm_coef, bool exact_step = false) {
     if (threadIdx.x == 0) {
         const float* a = s.sums[cur];
         float h[36], g[6];
@@ -1153,7 +1197,13 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
                 ++k;
             }
         Iso cand;
-        const bool ok = FAST ? lm_step_fast(h, g, model, lm_coef, &cand) : lm_step(h, g, model, lm_coef, &cand);
+        bool ok;
+        if constexpr (FAST && !VORS_ABL_EXACT_STEP) {
+            if (exact_step) ok = lm_step(h, g, model, lm_coef, &cand);  // (uniform; Geom::fused_exact_step, a development knob)
+            else ok = lm_step_fast(h, g, model, lm_coef, &cand);
+        } else {
+            ok = lm_step(h, g, model, lm_coef, &cand);
+        }
         iso_store(cand, s.cand);
         s.cand[7] = ok ? 1.0f : 0.0f;
     }
@@ -1202,7 +1252,7 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
     for (;;) {
         if (!have_cand) {
             nb_iter += 1;
-            solve_step_lane0<Src::FUSED>(s, cur, cur_model, lm_coef);  // step(): lm_optimizer.rs:123-136
+            solve_step_lane0<Src::FUSED>(s, cur, cur_model, lm_coef, c.exact_step);  // step(): lm_optimizer.rs:123-136
             if (uniform_f(s.cand[7]) == 0.0f) return false;
             cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
         }
@@ -1431,6 +1481,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         c.huber = g.huber_delta;
         c.inv_fu_d = g.lv[lvl].inv_fu_d; c.inv_fv_d = g.lv[lvl].inv_fv_d;
         c.inv_fu = g.lv[lvl].inv_fu; c.inv_fv = g.lv[lvl].inv_fv; c.s_fuv = g.lv[lvl].s_fuv;
+        if constexpr (FUSED) {
+            // Levels of FEW points run in the EXACT arithmetic (Geom::fused_exact_points): the energy of a few hundred points
+            // carries the per-point rounding of the fused warp (~1 ulp of u, v) at 3-10x the reference's own summation noise, enough to
+            // fork the accept / stop comparisons of the coarsest levels measurably more often (tools/parity_ablate.py); from a few
+            // thousand points on it averages out below that noise. (Workgroup-uniform.)
+            const int npts = DENSE ? g.lv[lvl].rows * g.lv[lvl].cols
+                                   : __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]);
+            c.force_exact = npts <= g.fused_exact_points;
+            c.exact_step = c.force_exact && g.fused_exact_step != 0;
+        }
         int nb_iter = 0, n_full = 0;
         float energy = 0.f, lm_coef = 0.f;
         bool ok = false;
@@ -1777,7 +1837,7 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws,
                         ++k;
                     }
                 Iso cand;
-                if (g.arith == VORS_ARITH_FUSED ? lm_step_fast(h, gr, cur_model, lm_coef, &cand) : lm_step(h, gr, cur_model, lm_coef, &cand)) {
+                if ((g.arith == VORS_ARITH_FUSED && !VORS_ABL_EXACT_STEP) ? lm_step_fast(h, gr, cur_model, lm_coef, &cand) : lm_step(h, gr, cur_model, lm_coef, &cand)) {
                     iso_store(cand, st->cand);
                     st->phase = 1;
                     again = true;

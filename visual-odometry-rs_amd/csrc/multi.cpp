@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     bool load(std::string* err) {
         if (lib) return true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -53,6 +55,7 @@ struct Rccl {
         VORS_SYM(GroupStart, "ncclGroupStart")
         VORS_SYM(GroupEnd, "ncclGroupEnd")
         VORS_SYM(GetErrorString, "ncclGetErrorString")
+        VORS_SYM(GetVersion, "ncclGetVersion")
 #undef VORS_SYM
         return true;
     }
@@ -165,6 +168,12 @@ vors_status vors_multi_create(const vors_config* cfg, int n_devices, const int* 
 
 int vors_multi_device_count(const vors_multi* m) { return m ? (int)m->sh.size() : 0; }
 
+int vors_multi_rccl_version(const vors_multi* m) {
+    int v = 0;
+    if (!m || m->sh.size() < 2 || !g_rccl.GetVersion || g_rccl.GetVersion(&v) != 0) return 0;
+    return v;
+}
+
 vors_status vors_multi_shard(const vors_multi* m, int n_pairs_total, int k, int* first, int* count) {
     if (!m || k < 0 || k >= (int)m->sh.size() || !first || !count) return vors_set_last_error(VORS_ERR_INVALID_ARGUMENT, "bad argument");
     const int nd = (int)m->sh.size(), per = (n_pairs_total + nd - 1) / nd;  // pair i -> device floor(i / ceil(n / G))
@@ -183,10 +192,17 @@ vors_status vors_multi_track_pairs(vors_multi* m, int n_pairs_total, const uint8
     if (n_pairs_total < 1 || per > m->per) return vors_set_last_error(VORS_ERR_INVALID_ARGUMENT, "n_pairs_total out of range for this handle");
     int prev = 0;
     (void)hipGetDevice(&prev);
+    // Whatever happens below, no stream of the handle has work in flight when this call returns: on an error path the other devices
+    // may already be running kernels that read the caller's buffers, so every shard stream is drained before the error is reported.
     struct Restore {
+        vors_multi* m;
         int d;
-        ~Restore() { (void)hipSetDevice(d); }
-    } restore{prev};
+        ~Restore() {
+            for (Shard& s : m->sh)
+                if (hipSetDevice(s.device) == hipSuccess) (void)hipStreamSynchronize(s.stream);
+            (void)hipSetDevice(d);
+        }
+    } restore{m, prev};
     // 1. every device tracks its block (concurrently: one stream per device, nothing is synchronised here)
     for (int k = 0; k < nd; ++k) {
         Shard& s = m->sh[k];
