@@ -48,8 +48,13 @@ enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1, VORS_CANDI
  * 0 = EXACT: every per-point expression in the reference's evaluation order without FMA contraction — inverse depths, Jacobians
  *     and per-point residuals are bit-identical to the reference's arithmetic (the parity anchor).
  * 1 = FUSED: algebraically equivalent shorter forms (warp through the homography K R K^-1 plus _z K t with one hardware
- *     reciprocal, lerp-form bilinear interpolation, factored Jacobian; FMA). Per-point values agree to a few ulp; poses agree with
- *     EXACT to ~1e-6 and stay within the 1e-4 rad / 1e-4 m parity bar (tests/test_gpu_parity.py runs both). About twice as fast. */
+ *     reciprocal, lerp-form bilinear interpolation, factored Jacobian; FMA) on the levels of MANY points; a level of at most 2500 points
+ *     (VORS_FUSED_EXACT_POINTS) and every near-identity model is evaluated in the EXACT arithmetic, because the energy of a few hundred
+ *     points carries the fused warp's per-point rounding above the reference's own summation noise and forks the LM path.
+ *     Per-point values agree to a few ulp. Parity statement (measured, 640x480 6 levels, bench.py `parity`): the fraction of pairs
+ *     beyond 1e-4 rad / 1e-4 m of the oracle equals that of EXACT and of the oracle against its own f64-accumulation build (~0.05 %:
+ *     pairs whose LM path forks on the ORDER of the f32 sums); it is NOT zero for any arithmetic, and pyramids of < 5 levels on large
+ *     images exceed 1e-4 from summation order alone (DESIGN.md §4 "short pyramids"). About 1.5-2x as fast as EXACT. */
 enum { VORS_ARITH_EXACT = 0, VORS_ARITH_FUSED = 1 };
 
 /* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
@@ -89,7 +94,8 @@ const char* vors_last_error(void);
 /* Number of visible HIP devices (0 when none / no runtime). Never fails. */
 int vors_device_count(void);
 /* ABI version of this header: bump on any signature change. */
-int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level */
+int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level
+                              * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces
@@ -109,6 +115,42 @@ vors_status vors_tracker_current_frame(const vors_tracker* t, double* timestamp,
 vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stats);
 vors_status vors_tracker_keyframe(const vors_tracker* t, double* timestamp, float pose7[7]);
 void vors_tracker_destroy(vors_tracker* t);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 1b. N sequences advancing in lock-step, device resident — what a host that tracks many cameras / many replays calls. For every
+ *     sequence s the calls below are exactly
+ *        tracker[s] = cfg.init(depth0[s], gray0[s])        vors_trackers_init     (vors_track.rs:46)
+ *        tracker[s].track(depth_k[s], gray_k[s])            vors_trackers_track    (vors_track.rs:54-59), k = 1, 2, ...
+ *        tracker[s].current_frame()                         vors_trackers_current_frames / _state  (vors_track.rs:62)
+ *     with the WHOLE state machine of Tracker::track on the device: the initial guess from the poses of the previous frame
+ *     (inverse_compositional.rs:177), the LM loop, the pose composition (:203-208), the optical-flow keyframe test (:211-224) and — for
+ *     exactly the sequences whose flow reached the threshold — the promotion of the current frame to keyframe (:227-239:
+ *     precompute_multires_data on the current pyramid and THIS call's depth map, keyframe_pose <- current_frame_pose). No host round
+ *     trip, no synchronisation: a call only enqueues work on hip_stream. Results per sequence are bit-identical to a vors_tracker fed
+ *     the same frames (tests/test_gpu_trackers.py).
+ *     Frames: DEVICE buffers, row-major, sequence s at offset s * rows * cols; they are read by the work this call enqueues and by
+ *     nothing later (dense mode copies a promoted frame into the handle), so the caller may reuse them once the stream has passed
+ *     the call. Timestamps stay with the caller: vors_trackers_state / _current_frames report, per sequence, the index of the frame
+ *     that is its keyframe (0 = the init frame, k = the k-th track call).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vors_trackers vors_trackers;
+vors_status vors_trackers_create(const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out);
+int vors_trackers_count(const vors_trackers* t);
+vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream);
+vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream);
+/* DEVICE pointers (valid for the life of the handle, contents valid once the stream has passed the last track call; all nullable):
+ * current_frame_pose [n,7], keyframe_pose [n,7], VORS_TRACK_* status of the last track [n], keyframe frame index [n], diagnostics of the
+ * last track [n]. */
+vors_status vors_trackers_state(const vors_trackers* t, const float** d_current_poses7, const float** d_keyframe_poses7,
+                                const int32_t** d_status, const int32_t** d_keyframe_index, const vors_pair_stats** d_stats);
+/* Same to HOST buffers (nullable each); synchronises hip_stream. */
+vors_status vors_trackers_current_frames(vors_trackers* t, float* poses7, int32_t* status, int32_t* keyframe_index, void* hip_stream);
+/* Diagnostics of the last track of every sequence to a HOST buffer [n]; synchronises hip_stream. */
+vors_status vors_trackers_last_stats(vors_trackers* t, vors_pair_stats* stats, void* hip_stream);
+/* Stage timing as for a batch handle (stages 1 = keyframe promotion, 2 = current pyramid, 3 = LM). */
+vors_status vors_trackers_enable_kernel_timing(vors_trackers* t, int ring);
+vors_status vors_trackers_kernel_times(vors_trackers* t, int stage, float* ms_out, int capacity, int* n_out);
+void vors_trackers_destroy(vors_trackers* t);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 2. Batch of independent frame pairs — the data-parallel hot path. For each pair p:
@@ -198,6 +240,8 @@ typedef struct vors_multi vors_multi;
 vors_status vors_multi_create(const vors_config* cfg, int n_devices, const int* device_ids, int max_pairs_per_device, int rows, int cols,
                               vors_multi** out);
 int vors_multi_device_count(const vors_multi* m);
+/* Version code of the RCCL the handle bound at run time (ncclGetVersion), 0 when the handle spans one device (RCCL not loaded). */
+int vors_multi_rccl_version(const vors_multi* m);
 /* Block of pairs owned by device slot k for a batch of n_pairs_total: [*first, *first + *count). */
 vors_status vors_multi_shard(const vors_multi* m, int n_pairs_total, int k, int* first, int* count);
 /* Device-resident: d_*[k] = device slot k's block (row-major images of ITS pairs, allocated on that device). Runs all devices
@@ -266,6 +310,11 @@ vors_status vors_synth_render_pairs(uint64_t seed0, int n_pairs, int rows, int c
                                     double motion_scale, int invalid_percent, uint8_t* d_kf_gray, uint16_t* d_kf_depth,
                                     uint8_t* d_cur_gray, uint16_t* d_cur_depth /* nullable */, float* d_gt_models7,
                                     void* hip_stream);
+
+/* Frames of the same scene at explicit twists (sequence tooling): frame f = scene seeds[f], depth-dropout salt salts[f], camera at
+ * exp(xi6[6 f .. 6 f + 5]) (twist (v, w), keyframe -> camera); host tables, DEVICE images [n_frames, rows, cols]. Synchronises. */
+vors_status vors_synth_render_frames(int n_frames, const uint64_t* seeds, const uint64_t* salts, const double* xi6, int rows, int cols,
+                                     const double cam5[5], int invalid_percent, uint8_t* d_gray, uint16_t* d_depth, void* hip_stream);
 
 #ifdef __cplusplus
 }

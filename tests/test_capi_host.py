@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(V.EXPORTED_SYMBOLS)
-    assert lib.vors_abi_version() == 2   # 2: vors_config.arithmetic
+    assert lib.vors_abi_version() == 3   # 3: vors_trackers_*, vors_synth_render_frames
 
 
 def test_struct_layouts_match_header():

@@ -235,7 +235,7 @@ int vors_device_count(void) {
     }
     return n;
 }
-int vors_abi_version(void) { return 2; }
+int vors_abi_version(void) { return 3; }
 
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
     int dev = 0;
@@ -850,6 +850,177 @@ void vors_tracker_destroy(vors_tracker* t) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// N sequences in lock-step, device resident (vors_trackers_*): the state machine of Tracker::track
+// (inverse_compositional.rs:170-240) for every sequence without a host round trip — initial guess from the poses kept on the device,
+// LM, pose composition, keyframe test, and the promotion of the current frame to keyframe for exactly the sequences whose optical flow
+// reached the threshold (masked launches of the keyframe stage over the list trackers_advance_kernel builds).
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct vors_trackers {
+    vors_batch* batch = nullptr;
+    int n_seq = 0;
+    int frame_index = 0;  // index of the last frame submitted (0 = the init frame)
+    bool initialised = false;
+    DevBuf cur_poses, kf_poses, out_poses, status, stats, kf_frame, promo_list, promo_count;
+    DevBuf own_gray, own_depth;  // dense mode: the keyframes' level 0 and depth maps (re-read by every evaluation) live in the handle
+    ~vors_trackers() { vors_batch_destroy(batch); }
+};
+
+extern "C" {
+
+vors_status vors_trackers_create(const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out) {
+    if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    vors_batch* b = nullptr;
+    vors_status st = vors_batch_create(cfg, n_sequences, rows, cols, &b);
+    if (st != VORS_OK) return st;
+    vors_trackers* t = new vors_trackers();
+    t->batch = b;
+    t->n_seq = n_sequences;
+    struct Guard {
+        vors_trackers* t;
+        ~Guard() { delete t; }
+    } guard{t};
+    const size_t n = (size_t)n_sequences, S = (size_t)rows * cols;
+    HIP_TRY(t->cur_poses.alloc(n * 7 * sizeof(float)));
+    HIP_TRY(t->kf_poses.alloc(n * 7 * sizeof(float)));
+    HIP_TRY(t->out_poses.alloc(n * 7 * sizeof(float)));
+    HIP_TRY(t->status.alloc(n * sizeof(int32_t)));
+    HIP_TRY(t->stats.alloc(n * sizeof(vors_pair_stats)));
+    HIP_TRY(t->kf_frame.alloc(n * sizeof(int32_t)));
+    HIP_TRY(t->promo_list.alloc(n * sizeof(int)));
+    HIP_TRY(t->promo_count.alloc(sizeof(int)));
+    if (b->g.mode == VORS_CANDIDATES_DENSE) {
+        HIP_TRY(t->own_gray.alloc(n * S));
+        HIP_TRY(t->own_depth.alloc(n * S * 2));
+    }
+    guard.t = nullptr;
+    *out = t;
+    return VORS_OK;
+}
+
+void vors_trackers_destroy(vors_trackers* t) {
+    if (!t) return;
+    DeviceGuard guard(t->batch ? t->batch->device : 0);
+    delete t;
+}
+
+int vors_trackers_count(const vors_trackers* t) { return t ? t->n_seq : 0; }
+
+vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream) {
+    if (!t || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    vors_batch* b = t->batch;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard guard(b->device);
+    vors_status st = check_stream(b, s);
+    if (st != VORS_OK) return st;
+    const size_t n = (size_t)t->n_seq, S = (size_t)b->g.S0;
+    const uint8_t* kf_gray = d_gray;
+    const uint16_t* kf_depth = d_depth;
+    if (b->g.mode == VORS_CANDIDATES_DENSE) {  // the handle's own copies (zero copy is impossible: keyframes outlive the caller's frames)
+        HIP_TRY(hipMemcpyAsync(t->own_gray.p, d_gray, n * S, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(t->own_depth.p, d_depth, n * S * 2, hipMemcpyDeviceToDevice, s));
+        kf_gray = t->own_gray.as<uint8_t>();
+        kf_depth = t->own_depth.as<uint16_t>();
+    }
+    st = vors_batch_prepare_keyframes(b, t->n_seq, kf_gray, kf_depth, s);
+    if (st != VORS_OK) return st;
+    // first frame: keyframe_pose = current_frame_pose = identity (inverse_compositional.rs:86-99)
+    std::vector<float> ident(n * 7, 0.f);
+    for (size_t i = 0; i < n; ++i) ident[7 * i + 6] = 1.f;
+    HIP_TRY(hipMemcpyAsync(t->cur_poses.p, ident.data(), n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->kf_poses.p, ident.data(), n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(t->kf_frame.p, 0, n * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(t->status.p, 0, n * sizeof(int32_t), s));
+    HIP_TRY(hipStreamSynchronize(s));  // (`ident` is pageable host memory)
+    t->frame_index = 0;
+    t->initialised = true;
+    return VORS_OK;
+}
+
+vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream) {
+    if (!t || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!t->initialised) return fail(VORS_ERR_INVALID_ARGUMENT, "vors_trackers_track called before vors_trackers_init");
+    vors_batch* b = t->batch;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard guard(b->device);
+    vors_status st = check_stream(b, s);
+    if (st != VORS_OK) return st;
+    const int n = t->n_seq;
+    t->frame_index += 1;
+    // Tracker::track up to the keyframe test (inverse_compositional.rs:177-224), all sequences
+    st = batch_track_current(b, n, d_gray, t->cur_poses.as<float>(), t->kf_poses.as<float>(), t->out_poses.as<float>(), t->status.as<int32_t>(),
+                             t->stats.as<vors_pair_stats>(), s);
+    if (st != VORS_OK) return st;
+    // :203-208 and :224-239 on the device: poses forward, promotion list
+    launch_trackers_advance(n, t->frame_index, t->out_poses.as<float>(), t->stats.as<vors_pair_stats>(), t->cur_poses.as<float>(),
+                            t->kf_poses.as<float>(), t->kf_frame.as<int32_t>(), t->promo_list.as<int>(), t->promo_count.as<int>(), s);
+    // precompute_multires_data (:230-235) for the promoted sequences only: the pyramid of the current frame is reused, the depth map is
+    // the one that came with it
+    Geom gm = b->g;
+    gm.sel_list = t->promo_list.as<int>();
+    gm.sel_count = t->promo_count.as<int>();
+    STAGE_BEGIN(b, 1, s);
+    if (b->g.mode == VORS_CANDIDATES_DENSE) {
+        const size_t S = (size_t)b->g.S0;
+        launch_promote_copy(gm, d_gray, S, t->own_gray.p, S, S, n, s);
+        launch_promote_copy(gm, d_depth, 2 * S, t->own_depth.p, 2 * S, 2 * S, n, s);
+        launch_promote_copy(gm, b->cur_upper, (size_t)b->g.upper_stride, b->kf_upper, (size_t)b->g.upper_stride, (size_t)b->g.upper_stride, n, s);
+        launch_keyframe(gm, Pyramid{t->own_gray.as<uint8_t>(), b->kf_upper}, t->own_depth.as<uint16_t>(), b->rec, n, s);
+    } else if (b->g.mode == VORS_CANDIDATES_DSO) {
+        launch_keyframe_dso(gm, Pyramid{d_gray, b->cur_upper}, d_depth, b->dso, b->mask0, b->pp, b->rec, n, s);
+    } else {
+        launch_keyframe(gm, Pyramid{d_gray, b->cur_upper}, d_depth, b->rec, n, s);
+    }
+    STAGE_END(b, 1, s);
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+vors_status vors_trackers_state(const vors_trackers* t, const float** d_current_poses7, const float** d_keyframe_poses7,
+                                const int32_t** d_status, const int32_t** d_keyframe_index, const vors_pair_stats** d_stats) {
+    if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (d_current_poses7) *d_current_poses7 = static_cast<const float*>(t->cur_poses.p);
+    if (d_keyframe_poses7) *d_keyframe_poses7 = static_cast<const float*>(t->kf_poses.p);
+    if (d_status) *d_status = static_cast<const int32_t*>(t->status.p);
+    if (d_keyframe_index) *d_keyframe_index = static_cast<const int32_t*>(t->kf_frame.p);
+    if (d_stats) *d_stats = static_cast<const vors_pair_stats*>(t->stats.p);
+    return VORS_OK;
+}
+
+vors_status vors_trackers_current_frames(vors_trackers* t, float* poses7, int32_t* status, int32_t* keyframe_index, void* hip_stream) {
+    if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard guard(t->batch->device);
+    const size_t n = (size_t)t->n_seq;
+    if (poses7) HIP_TRY(hipMemcpyAsync(poses7, t->cur_poses.p, n * 7 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, t->status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (keyframe_index) HIP_TRY(hipMemcpyAsync(keyframe_index, t->kf_frame.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VORS_OK;
+}
+
+vors_status vors_trackers_last_stats(vors_trackers* t, vors_pair_stats* stats, void* hip_stream) {
+    if (!t || !stats) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (t->frame_index < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "no frame has been tracked yet");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard guard(t->batch->device);
+    HIP_TRY(hipMemcpyAsync(stats, t->stats.p, (size_t)t->n_seq * sizeof(vors_pair_stats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VORS_OK;
+}
+
+vors_status vors_trackers_enable_kernel_timing(vors_trackers* t, int ring) {
+    if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    return vors_batch_enable_kernel_timing(t->batch, ring);
+}
+vors_status vors_trackers_kernel_times(vors_trackers* t, int stage, float* ms_out, int capacity, int* n_out) {
+    if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    return vors_batch_kernel_times(t->batch, stage, ms_out, capacity, n_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // operator level
 // ---------------------------------------------------------------------------------------------------------------
 struct ObsDev {
@@ -974,6 +1145,32 @@ vors_status vors_synth_render_pairs(uint64_t seed0, int n_pairs, int rows, int c
     if (st != VORS_OK) return st;
     launch_synth_pairs(seed0, n_pairs, rows, cols, cam5, motion_scale, invalid_percent, d_kf_gray, d_kf_depth, d_cur_gray,
                        d_cur_depth, d_gt_models7, static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+vors_status vors_synth_render_frames(int n_frames, const uint64_t* seeds, const uint64_t* salts, const double* xi6, int rows, int cols,
+                                     const double cam5[5], int invalid_percent, uint8_t* d_gray, uint16_t* d_depth, void* hip_stream) {
+    if (!seeds || !salts || !xi6 || !cam5 || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_frames < 1 || rows < 1 || cols < 1) return fail(VORS_ERR_INVALID_ARGUMENT, "bad shape");
+    vors_status st = require_device();
+    if (st != VORS_OK) return st;
+    struct Frame {
+        uint64_t seed, salt;
+        double xi[6];
+    };
+    std::vector<Frame> h((size_t)n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        h[f].seed = seeds[f];
+        h[f].salt = salts[f];
+        for (int q = 0; q < 6; ++q) h[f].xi[q] = xi6[6 * f + q];
+    }
+    DevBuf d;
+    HIP_TRY(d.alloc(h.size() * sizeof(Frame)));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(Frame), hipMemcpyHostToDevice, s));
+    launch_synth_frames(d.p, n_frames, rows, cols, cam5, invalid_percent, d_gray, d_depth, s);
+    HIP_TRY(hipStreamSynchronize(s));  // (the table is freed on return)
     HIP_TRY(hipGetLastError());
     return VORS_OK;
 }

@@ -102,7 +102,10 @@ EXPORTED_SYMBOLS = [
     "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
     "vors_synth_render_pairs",
     "vors_multi_create", "vors_multi_device_count", "vors_multi_shard", "vors_multi_track_pairs", "vors_multi_track_pairs_host",
-    "vors_multi_destroy",
+    "vors_multi_destroy", "vors_multi_rccl_version",
+    "vors_trackers_create", "vors_trackers_count", "vors_trackers_init", "vors_trackers_track", "vors_trackers_state",
+    "vors_trackers_current_frames", "vors_trackers_last_stats", "vors_trackers_enable_kernel_timing", "vors_trackers_kernel_times", "vors_trackers_destroy",
+    "vors_synth_render_frames",
 ]
 
 _lib = None
@@ -143,6 +146,19 @@ def lib():
         _lib.vors_multi_track_pairs_host.argtypes = [vp, i, vp, vp, vp, vp, vp]
         _lib.vors_multi_destroy.argtypes = [vp]
         _lib.vors_multi_destroy.restype = None
+        _lib.vors_multi_rccl_version.argtypes = [vp]
+        _lib.vors_trackers_create.argtypes = [C.POINTER(vors_config), i, i, i, C.POINTER(vp)]
+        _lib.vors_trackers_count.argtypes = [vp]
+        _lib.vors_trackers_init.argtypes = [vp, vp, vp, vp]
+        _lib.vors_trackers_track.argtypes = [vp, vp, vp, vp]
+        _lib.vors_trackers_state.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        _lib.vors_trackers_current_frames.argtypes = [vp, vp, vp, vp, vp]
+        _lib.vors_trackers_last_stats.argtypes = [vp, vp, vp]
+        _lib.vors_trackers_enable_kernel_timing.argtypes = [vp, i]
+        _lib.vors_trackers_kernel_times.argtypes = [vp, i, vp, i, C.POINTER(i)]
+        _lib.vors_trackers_destroy.argtypes = [vp]
+        _lib.vors_trackers_destroy.restype = None
+        _lib.vors_synth_render_frames.argtypes = [i, vp, vp, vp, i, i, vp, i, vp, vp, vp]
         _lib.vors_batch_track_pairs.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib.vors_batch_prepare_keyframes.argtypes = [vp, i, vp, vp, vp]
         _lib.vors_batch_track_current.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
@@ -313,6 +329,7 @@ class MultiGpu:
         self._h = C.c_void_p()
         cfg = config.to_c()
         ids = np.ascontiguousarray(device_ids, np.int32) if device_ids is not None else None
+        self._device_ids = [int(x) for x in device_ids] if device_ids is not None else None
         _check(lib().vors_multi_create(C.byref(cfg), n_devices, _ptr(ids), max_pairs_per_device, rows, cols, C.byref(self._h)))
 
     def __del__(self):
@@ -326,6 +343,13 @@ class MultiGpu:
     def device_count(self):
         return lib().vors_multi_device_count(self._h)
 
+    def rccl_version(self):
+        """ncclGetVersion of the RCCL bound at run time; 0 for a one-device handle (RCCL is not loaded then)."""
+        return lib().vors_multi_rccl_version(self._h)
+
+    def _device_of(self, k):
+        return self._device_ids[k] if self._device_ids is not None else k
+
     def shard(self, n_total, k):
         a, b = C.c_int(), C.c_int()
         _check(lib().vors_multi_shard(self._h, n_total, k, C.byref(a), C.byref(b)))
@@ -336,8 +360,9 @@ class MultiGpu:
         kf_depth = np.ascontiguousarray(kf_depth, np.uint16)
         cur_gray = np.ascontiguousarray(cur_gray, np.uint8)
         n = kf_gray.shape[0]
-        if kf_gray.shape[1:] != (self.rows, self.cols):
-            raise VorsError(f"expected [n, {self.rows}, {self.cols}] images, got {kf_gray.shape}")
+        for name, a in (("kf_gray", kf_gray), ("kf_depth", kf_depth), ("cur_gray", cur_gray)):  # the C ABI reads n * rows * cols of each
+            if a.shape != (n, self.rows, self.cols):
+                raise VorsError(f"{name}: expected [{n}, {self.rows}, {self.cols}] images, got {a.shape}")
         poses = np.zeros((n, 7), np.float32)
         status = np.zeros(n, np.int32)
         _check(lib().vors_multi_track_pairs_host(self._h, n, _ptr(kf_gray), _ptr(kf_depth), _ptr(cur_gray), _ptr(poses), _ptr(status)))
@@ -346,6 +371,14 @@ class MultiGpu:
     def track_pairs(self, shards_kf_gray, shards_kf_depth, shards_cur_gray, n_total):
         """Device-resident: one torch tensor per device slot (that device's block of pairs)."""
         nd = self.device_count()
+        for ts in (shards_kf_gray, shards_kf_depth, shards_cur_gray):
+            if len(ts) != nd:
+                raise VorsError(f"expected {nd} shards, got {len(ts)}")
+            for k, t in enumerate(ts):
+                cnt = self.shard(n_total, k)[1]
+                if cnt and (t is None or tuple(t.shape) != (cnt, self.rows, self.cols) or not t.is_contiguous() or t.device.index != self._device_of(k)):
+                    raise VorsError(f"shard {k}: expected a contiguous [{cnt}, {self.rows}, {self.cols}] tensor on device slot {k}, got "
+                                    f"{None if t is None else (tuple(t.shape), t.device)}")
         arr = lambda ts: (C.c_void_p * nd)(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
         poses = np.zeros((n_total, 7), np.float32)
         status = np.zeros(n_total, np.int32)
@@ -474,6 +507,80 @@ class Batch:
         _check(lib().vors_batch_get_points(self._h, pair, level, cap, _ptr(xy), _ptr(iz), _ptr(jac), _ptr(tm), C.byref(n)))
         n = n.value
         return xy[:n].copy(), iz[:n].copy(), jac[:n].copy(), tm[:n].copy()
+
+
+class Trackers:
+    """N sequences in lock-step, device resident (vors_trackers_*): Config::init / Tracker::track / current_frame for every
+    sequence with the whole tracker state machine (poses, keyframe test, per-sequence keyframe promotion) on the device."""
+
+    def __init__(self, config, n_sequences, rows, cols):
+        self.config, self.n, self.rows, self.cols = config, n_sequences, rows, cols
+        self._h = C.c_void_p()
+        cfg = config.to_c()
+        _check(lib().vors_trackers_create(C.byref(cfg), n_sequences, rows, cols, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vors_trackers_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _check_frames(self, gray, depth):
+        for t in (gray, depth):
+            if tuple(t.shape) != (self.n, self.rows, self.cols) or not t.is_contiguous():
+                raise VorsError(f"expected contiguous [{self.n}, {self.rows}, {self.cols}] frames, got {tuple(t.shape)}")
+
+    def init(self, gray, depth):
+        """Config::init for every sequence (frame 0)."""
+        self._check_frames(gray, depth)
+        _check(lib().vors_trackers_init(self._h, Batch._dp(gray), Batch._dp(depth), Batch._stream()))
+
+    def track(self, gray, depth):
+        """Tracker::track for every sequence (one new frame each); only enqueues work on torch's current stream."""
+        self._check_frames(gray, depth)
+        self._last = (gray, depth)  # keep the frames alive until the next call (the enqueued work reads them)
+        _check(lib().vors_trackers_track(self._h, Batch._dp(gray), Batch._dp(depth), Batch._stream()))
+
+    def current_frames(self):
+        """-> (poses7 [n,7], status [n], keyframe frame index [n]) on the host; synchronises the current stream."""
+        poses = np.zeros((self.n, 7), np.float32)
+        status = np.zeros(self.n, np.int32)
+        kf = np.zeros(self.n, np.int32)
+        _check(lib().vors_trackers_current_frames(self._h, _ptr(poses), _ptr(status), _ptr(kf), Batch._stream()))
+        return poses, status, kf
+
+    def stats(self):
+        """Diagnostics of the last track() of every sequence (host copy; synchronises the current stream)."""
+        out = np.zeros(self.n, PAIR_STATS_DTYPE)
+        _check(lib().vors_trackers_last_stats(self._h, _ptr(out), Batch._stream()))
+        return out
+
+    def enable_kernel_timing(self, ring=64):
+        _check(lib().vors_trackers_enable_kernel_timing(self._h, int(ring)))
+
+    def kernel_times(self, stage):
+        out = np.zeros(4096, np.float32)
+        n = C.c_int()
+        _check(lib().vors_trackers_kernel_times(self._h, Batch.STAGES[stage], _ptr(out), 4096, C.byref(n)))
+        return out[:n.value].copy()
+
+
+def synth_render_frames(seeds, salts, xis, rows, cols, cam5, invalid_percent=2, device="cuda"):
+    """Frames of the synthetic scene at explicit twists (vors_synth_render_frames) -> gray u8 [n,rows,cols], depth (int16 payload u16)."""
+    import torch
+    seeds = np.ascontiguousarray(seeds, np.uint64)
+    salts = np.ascontiguousarray(salts, np.uint64)
+    xis = np.ascontiguousarray(xis, np.float64).reshape(-1, 6)
+    n = len(seeds)
+    assert len(salts) == n and len(xis) == n
+    gray = torch.empty((n, rows, cols), dtype=torch.uint8, device=device)
+    depth = torch.empty((n, rows, cols), dtype=torch.int16, device=device)
+    cam = np.asarray(cam5, np.float64)
+    _check(lib().vors_synth_render_frames(n, _ptr(seeds), _ptr(salts), _ptr(xis), rows, cols, _ptr(cam), invalid_percent,
+                                          Batch._dp(gray), Batch._dp(depth), Batch._stream()))
+    return gray, depth
 
 
 def stats_tensor(n, device="cuda"):
