@@ -55,6 +55,11 @@ def parse():
                    help="per-point arithmetic (include/vors_hip.h VORS_ARITH_*): fused = equivalent shorter f32 forms (poses within the 1e-4 "
                         "parity bar, gated by tests/test_gpu_fused.py); exact = the reference's evaluation order (parity anchor)")
     p.add_argument("--cpu-pairs", type=int, default=-1, help="pairs timed on the CPU oracle (-1 = auto, 0 = skip)")
+    p.add_argument("--parity-pairs", type=int, default=-1,
+                   help="pairs of each measured workload compared with the oracle after the timed region (-1 = auto: 1024 dense / 4096 sparse on a "
+                        "many-core host, 0 = skip)")
+    p.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then falls back to the committed profile)")
+    p.add_argument("--no-sequences", action="store_true", help="skip the 64-sequence tracker measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other candidate mode, 256-pair batch)")
     p.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (kernel timing off)")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -76,15 +81,84 @@ def byte_model(stats, L, rows, cols, dense):
     return b_io, b_lm, b_flat_total, float(evals.sum(1).mean()), float((evals * n_pts).sum(1).mean())
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel + engine sources: what a committed counter profile must have been taken from to describe
+    THIS build (tools/summarize_prof.py stamps the same hash into profiles/lm_counters.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "visual-odometry-rs_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def lm_counters(args):
     """Counters of the LM stage of one step of THIS workload from the committed rocprofv3 PMC passes (profiles/lm_counters.json,
-    written by tools/make_lm_counters.py from `tools/profile.sh` + `tools/pmc_sq.sh` output), or {} when none was taken."""
+    written by tools/make_lm_counters.py from `tools/profile.sh` output) — only when that profile was taken from the very sources this
+    build comes from (`source_sha16` stamp); {} otherwise."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "lm_counters.json")))
     except Exception:
         return {}
     key = f"{args.candidates}_{args.arith}_{args.cols}x{args.rows}_L{args.levels}_{args.pairs}pairs" + (f"_huber{args.huber:g}" if args.huber > 0 else "")
-    return table.get(key, {})
+    e = table.get(key, {})
+    if not e or e.get("source_sha16") != kernel_source_hash():
+        return {}
+    e = dict(e)
+    e["source"] = f"from_profile: {e.get('profile')} (same kernel sources: sha16 {e['source_sha16']})"
+    return e
+
+
+LM_STAGE_KERNELS = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel")
+ONCE_PER_STEP_KERNELS = ("dense_idepth_level1", "keyframe_sparse_kernel", "dso_rounds_kernel")  # launched exactly once per bench step
+
+
+def live_counters(args):
+    """HBM traffic and VALU counters of the LM stage of one step, MEASURED IN THIS RUN: three short rocprofv3 passes of this very command
+    (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`; each its own process with --kernel-trace only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), 2 steps each, after the timed region.
+    traffic = FETCH_SIZE KiB x 2 (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE KiB. {} if rocprofv3 is missing / fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {}
+    child = [sys.executable, os.path.abspath(__file__), "--pairs", str(args.pairs), "--steps", "2", "--warmup", "1", "--candidates", args.candidates,
+             "--arith", args.arith, "--rows", str(args.rows), "--cols", str(args.cols), "--levels", str(args.levels), "--huber", str(args.huber),
+             "--no-secondary", "--cpu-pairs", "0", "--parity-pairs", "0", "--no-pmc", "--no-sequences"]
+    out, t0 = {}, time.perf_counter()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]):
+        d = tempfile.mkdtemp(prefix="vors_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "b", "--"] + child,
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                continue
+            agg, steps = {}, {}
+            for r in csv.DictReader(open(files[0])):
+                name, c = r["Kernel_Name"], r["Counter_Name"]
+                if any(k in name for k in LM_STAGE_KERNELS):
+                    agg[c] = agg.get(c, 0.0) + float(r["Counter_Value"])
+                if any(k in name for k in ONCE_PER_STEP_KERNELS):
+                    steps[c] = steps.get(c, 0) + 1
+            for c, v in agg.items():
+                if steps.get(c):
+                    out[c.lower()] = v / steps[c]
+        except Exception:
+            pass
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "fetch_size" in out and "write_size" in out:
+        out["traffic_bytes"] = int(out["fetch_size"] * 1024 * 2 + out["write_size"] * 1024)
+    if out:
+        out["source"] = (f"measured in this run: rocprofv3 --pmc passes of this command (2 steps each, {time.perf_counter() - t0:.0f} s); "
+                         "FETCH_SIZE KiB x 2 + WRITE_SIZE KiB per MI355X_MICROARCH.md")
+    return out
 
 
 class Workload:
@@ -157,11 +231,14 @@ def timed_run(work, steps, warmup, world, packed, gathered):
     return dt
 
 
-def cpu_baseline_and_parity(args, work, value):
+def host_pairs(work, n):
+    return (work.kg[:n].cpu().numpy(), work.kd[:n].cpu().numpy().view(np.uint16), work.cg[:n].cpu().numpy())
+
+
+def cpu_baseline(args, work, value):
     """the oracle (C++ restatement of the reference, `kind: port`) on a bounded sample of the same pairs — a
     -march=native build made on THIS host (FMA contraction stays off: the arithmetic is the oracle's), one pinned thread like the
-    single-threaded reference, 1 warm-up + median of 5 runs; plus an all-cores figure. The same sample is the parity check of the run:
-    GPU poses vs oracle, branch-flip rate, and the f64-accumulation probe of the oracle (how much the f32 summation order decides)."""
+    single-threaded reference, 1 warm-up + median of 5 runs; plus an all-cores figure."""
     from oracle import oracle as O
     dense = args.candidates == "dense"
     n_cpu = args.cpu_pairs
@@ -170,9 +247,7 @@ def cpu_baseline_and_parity(args, work, value):
         scale = (args.rows * args.cols) / (480.0 * 640.0)
         n_cpu = max(4, int(n_cpu / scale))
     n_cpu = min(n_cpu, work.n)
-    kg = work.kg[:n_cpu].cpu().numpy()
-    kd = work.kd[:n_cpu].cpu().numpy().view(np.uint16)
-    cg = work.cg[:n_cpu].cpu().numpy()
+    kg, kd, cg = host_pairs(work, n_cpu)
     ocfg = O.make_config(args.levels, work.intr, candidates_mode=work.mode_id, huber_delta=args.huber)
     ncores = os.cpu_count() or 1
     pinned = None
@@ -199,14 +274,7 @@ def cpu_baseline_and_parity(args, work, value):
         O.track_pairs(ocfg, kg, kd, cg, n_threads=min(ncores, n_cpu), variant="native")
         all_runs.append(time.perf_counter() - t0)
     t_all = float(np.median(all_runs))
-    # parity of this run (the oracle proper: baseline x86-64 build, no FMA)
-    ref = O.track_pairs(ocfg, kg, kd, cg, n_threads=min(ncores, n_cpu))
-    ref64 = O.track_pairs(ocfg, kg, kd, cg, n_threads=min(ncores, n_cpu), variant="acc64")
-    gpu_poses = work.poses[:n_cpu].cpu().numpy()
-    st = work.V.decode_stats(work.stats)[:n_cpu]
-    L = args.levels
-    ok = ref["status"] == 0
-    cpu = {
+    return {
         "value": round(n_cpu / t_cpu, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
         "sample": f"first {n_cpu} pairs of the same batch, same candidates mode; oracle/ C++ restatement of the reference built on this host with "
                   f"-O3 -march=native (no FMA contraction, no fast-math), ONE thread pinned to core {pinned} like the single-threaded reference; "
@@ -214,16 +282,167 @@ def cpu_baseline_and_parity(args, work, value):
         "all_cores": {"value": round(n_cpu / t_all, 3), "cores": min(ncores, n_cpu), "note": "one thread per contiguous block of pairs, median of 3"},
         "gpu_over_cpu_1core": round(value / (n_cpu / t_cpu), 1),
     }
-    parity = {
-        "sample_pairs": n_cpu,
-        "max_pose_diff_gpu_vs_oracle": float(np.abs(gpu_poses - ref["poses"])[ok].max(initial=0.0)),
-        "status_equal": bool((work.status[:n_cpu].cpu().numpy() == ref["status"]).all()),
+
+
+def parity_block(args, work, n_want):
+    """FULL-BATCH parity of the timed arithmetic: the poses the timed steps produced for the first n pairs of the
+    batch against the oracle proper (baseline x86-64 build, no FMA) run on all host cores, with the tail made visible — pairs beyond
+    the 1e-4 tolerance, p99, max — and beside it the oracle against its OWN f64-accumulation build on the same pairs: the floor set by
+    the order of the reference's f32 sums, which no implementation that sums in another order can beat."""
+    from oracle import oracle as O
+    ncores = os.cpu_count() or 1
+    n = min(n_want, work.n)
+    kg, kd, cg = host_pairs(work, n)
+    ocfg = O.make_config(args.levels, work.intr, candidates_mode=work.mode_id, huber_delta=args.huber)
+    t0 = time.perf_counter()
+    ref = O.track_pairs(ocfg, kg, kd, cg, n_threads=min(ncores, n))
+    t_oracle = time.perf_counter() - t0
+    ref64 = O.track_pairs(ocfg, kg, kd, cg, n_threads=min(ncores, n), variant="acc64")
+    gpu_poses = work.poses[:n].cpu().numpy()
+    st = work.V.decode_stats(work.stats)[:n]
+    L = args.levels
+    ok = ref["status"] == 0
+    err = np.abs(gpu_poses - ref["poses"]).max(axis=1)
+    err64 = np.abs(ref64["poses"] - ref["poses"]).max(axis=1)
+    err[~ok] = 0.0     # a failed pair keeps its previous pose in both (status equality is reported separately)
+    err64[~ok] = 0.0
+    q = np.quantile(err, [0.5, 0.99])
+    return {
+        "candidates": work.mode, "arithmetic": args.arith, "sample_pairs": int(n), "tolerance": 1e-4,
+        "n_beyond_tol": int((err > 1e-4).sum()),
+        "n_beyond_tol_oracle_f32_vs_f64_accumulation": int((err64 > 1e-4).sum()),
+        "median_pose_diff": float(q[0]), "p99_pose_diff": float(q[1]), "max_pose_diff_gpu_vs_oracle": float(err.max(initial=0.0)),
+        "max_pose_diff_oracle_f32_vs_f64_accumulation": float(err64.max(initial=0.0)),
+        "status_equal": bool((work.status[:n].cpu().numpy() == ref["status"]).all()),
         "branch_flip_rate_gpu_vs_oracle": float((st["nb_iter"][:, :L] != ref["nb_iter"]).any(axis=1).mean()),
-        "max_pose_diff_oracle_f32_vs_f64_accumulation": float(np.abs(ref64["poses"] - ref["poses"])[ok].max(initial=0.0)),
         "branch_flip_rate_oracle_f32_vs_f64_accumulation": float((ref64["nb_iter"] != ref["nb_iter"]).any(axis=1).mean()),
-        "tolerance": 1e-4,
+        "oracle_seconds_all_cores": round(t_oracle, 2), "oracle_threads": min(ncores, n),
     }
-    return cpu, parity
+
+
+def multi_gpu_self_check(args, work, packed, gathered, rank, world):
+    """First-run safety of the N > 1 path (it has never executed on real multi-GPU hardware before the driver's SCALE run): after the
+    timed region every rank checks that block r of the gathered [world * P, 8] table equals rank r's local results — its own block
+    against its own poses / statuses, and (through one more all-gather of a per-rank checksum) every other block against its owner's —
+    and that the collective library answers its version query. Raises on any mismatch: a wrong gather must fail loudly, not time well."""
+    import torch.distributed as dist
+    P = args.pairs
+    local = torch.empty((P, 8), dtype=torch.float32, device=packed.device)
+    local[:, :7] = work.poses
+    local[:, 7] = work.status
+    mine = gathered[rank * P:(rank + 1) * P]
+    if not torch.equal(mine, local):
+        raise SystemExit(f"rank {rank}: its block of the gathered table differs from its local results")
+    # a checksum of every block as each rank sees it vs the owner's checksum of its local table
+    sums_seen = gathered.view(world, P * 8).double().sum(dim=1)
+    own = local.double().sum().reshape(1)
+    owners = [torch.zeros(1, dtype=torch.float64, device=packed.device) for _ in range(world)]
+    if dist.get_backend() == "nccl":
+        dist.all_gather(owners, own)
+    else:
+        cpu_owners = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(cpu_owners, own.cpu())
+        owners = [o.to(packed.device) for o in cpu_owners]
+    owners = torch.cat(owners)
+    if not torch.equal(sums_seen, owners):
+        raise SystemExit(f"rank {rank}: gathered blocks differ from their owners' results: {sums_seen.tolist()} vs {owners.tolist()}")
+    ver = None
+    if dist.get_backend() == "nccl":
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())  # RCCL's ncclGetVersion through torch
+        if not ver:
+            raise SystemExit("RCCL version query failed")
+    return {"gathered_blocks_equal_owners": True, "ranks": world, "rccl_version": ver, "backend": dist.get_backend()}
+
+
+def sequences_bench(V, args, device, n_seq=64, n_frames=40):
+    """configs[0] / configs[2]'s shape — SEQUENCES, not pairs: 64 sequences of 40 frames advancing in lock-step through vors_trackers_*
+    (the whole Tracker::track state machine incl. per-sequence keyframe promotion on the device, no host round trip), frames resident in
+    HBM; beside it the CPU oracle's Tracker on ONE pinned core over one of the sequences, and the pose agreement on all of them."""
+    from oracle import oracle as O
+    rows, cols, L = args.rows, args.cols, args.levels
+    intr = V.scaled_intrinsics(rows, cols)
+    base = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
+    rng = np.random.default_rng(11)
+    speed = 0.5 + 1.0 * rng.random(n_seq)
+    sign = rng.choice([-1.0, 1.0], size=(n_seq, 6))
+    out = {}
+    for mode in ("c2f", "dso"):
+        blocky = (1 << 63) if mode == "dso" else 0
+        frames = []
+        for k in range(n_frames):
+            frames.append(V.synth_render_frames([blocky | (4242 + s) for s in range(n_seq)], [k] * n_seq,
+                                                [base * sign[s] * speed[s] * k for s in range(n_seq)], rows, cols, intr, device=device))
+        mode_id = {"c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO}[mode]
+        cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode_id,
+                       arithmetic=V.ARITH_FUSED if args.arith == "fused" else V.ARITH_EXACT)
+        tr = V.Trackers(cfg, n_seq, rows, cols)
+        for _ in range(2):  # the first pass warms up; the second is timed
+            tr.init(*frames[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(1, n_frames):
+                tr.track(*frames[k])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        # one more pass that reads the poses back every frame (what a host that writes trajectories does): the parity trajectory
+        tr.init(*frames[0])
+        traj, switches, kf_prev = [], 0, np.zeros(n_seq, np.int32)
+        for k in range(1, n_frames):
+            tr.track(*frames[k])
+            poses, status, kf = tr.current_frames()
+            traj.append(poses)
+            switches += int((kf != kf_prev).sum())
+            kf_prev = kf
+        # CPU oracle tracker, one pinned core, on the first sequences; parity over them
+        n_cpu = min(n_seq, max(1, (os.cpu_count() or 1) // 4))
+        host = [(g[:n_cpu].cpu().numpy(), d[:n_cpu].cpu().numpy().view(np.uint16)) for g, d in frames]
+        ocfg = O.make_config(L, intr, candidates_mode=mode_id)
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, {allowed[len(allowed) // 2]})
+        except (AttributeError, OSError):
+            allowed = None
+        try:
+            t0 = time.perf_counter()
+            ot = O.Tracker(ocfg, 0.0, host[0][1][0], 0.0, host[0][0][0], keep_debug=False)
+            ref0 = []
+            for k in range(1, n_frames):
+                ot.track(float(k), host[k][1][0], float(k), host[k][0][0])
+                ref0.append(ot.current_frame()[1])
+            t_cpu = time.perf_counter() - t0
+        finally:
+            if allowed is not None:
+                os.sched_setaffinity(0, set(allowed))
+        errs = [float(np.abs(np.array(ref0) - np.array([p[0] for p in traj])).max())]
+        for sidx in range(1, n_cpu):
+            ot = O.Tracker(ocfg, 0.0, host[0][1][sidx], 0.0, host[0][0][sidx], keep_debug=False)
+            e = 0.0
+            for k in range(1, n_frames):
+                ot.track(float(k), host[k][1][sidx], float(k), host[k][0][sidx])
+                e = max(e, float(np.abs(ot.current_frame()[1] - traj[k - 1][sidx]).max()))
+            errs.append(e)
+        fps = n_seq * (n_frames - 1) / dt
+        cpu_fps = (n_frames - 1) / t_cpu
+        out[mode] = {"frames_per_s": round(fps, 1), "ms_per_lockstep_frame": round(dt / (n_frames - 1) * 1e3, 4), "sequences": n_seq,
+                     "frames_per_sequence": n_frames - 1, "keyframe_switches": switches,
+                     "cpu_oracle_tracker_frames_per_s_1core": round(cpu_fps, 1), "gpu_over_cpu_1core": round(fps / cpu_fps, 1),
+                     "max_pose_diff_vs_oracle_tracker": float(max(errs)), "sequences_compared": n_cpu,
+                     "n_sequences_beyond_tol": int(sum(e > 1e-4 for e in errs))}
+        del tr, frames
+    out["note"] = (f"{args.cols}x{args.rows}, {L} levels, {args.arith} arithmetic; frames resident in HBM; a lock-step frame = one vors_trackers_track call "
+                   "for all 64 sequences; the trajectory error is the max over all frames of a sequence (errors accumulate along a sequence)")
+    return out
+
+
+def parity_sample_sizes(args):
+    """Pairs compared per candidates mode: 1024 dense / 4096 sparse at 640x480 on a many-core host (the oracle takes ~15 s / ~3 s on 256
+    threads), scaled down with the host's core count and up-sized images so that the default run stays within minutes."""
+    if args.parity_pairs >= 0:
+        return {"dense": args.parity_pairs, "c2f": args.parity_pairs, "dso": args.parity_pairs}
+    ncores = os.cpu_count() or 1
+    scale = (args.rows * args.cols) / (480.0 * 640.0)
+    return {"dense": int(max(48, min(1024, 4 * ncores)) / scale), "c2f": int(max(192, min(4096, 16 * ncores)) / scale),
+            "dso": int(max(192, min(4096, 16 * ncores)) / scale)}
 
 
 def main():
@@ -283,11 +502,20 @@ def main():
     achieved = lm_bytes / lm_avg_s / 1e9
     job_gbps = (b_io + b_lm) * world * args.steps / dt / 1e9
     gt_err = np.abs(stats["lm_model"] - main_w.gt.cpu().numpy()).max(axis=1)
-    cnt = lm_counters(args)
+    cnt = {}
+    if rank == 0 and world == 1 and not args.no_pmc:
+        cnt = live_counters(args)
+    if "traffic_bytes" not in cnt:
+        cnt = lm_counters(args) or cnt
+    clock_hz = torch.cuda.get_device_properties(dev_index).clock_rate * 1e3  # hipDeviceAttributeClockRate (kHz): the peak shader clock
     base_shape = (args.rows, args.cols, args.levels) == (480, 640, 6)
 
+    traffic = cnt.get("traffic_bytes")
     roofline = {
-        "bound": "hbm",
+        # What binds the dominant stage is VALU issue, not the memory system (memory_side_frac below); `frac` stays what SURVEY §8(d)
+        # defines — algorithmic bytes over the stage's measured time against the 8 TB/s HBM roofline.
+        "bound": "valu",
+        "model": "hbm: SURVEY §8(d) algorithmic bytes / measured stage time vs 8 TB/s",
         # dense mode: the LM stage is a short sequence of launches (coarse levels per pair, then one launch per energy evaluation round on
         # the finest levels + a per-pair step launch, then the per-pair epilogue); it is timed as a whole with HIP events on its stream,
         # and its algorithmic bytes are those of all its evaluations
@@ -297,10 +525,12 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 5),
-        # HBM bytes of the same stage from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; separate rocprofv3 --pmc passes of this
-        # exact command, committed under profiles/): NOT measured in this run — null when no profile of this workload exists
-        "traffic": cnt.get("traffic_bytes"),
-        "traffic_source": cnt.get("profile", None) and f"from_profile: {cnt['profile']}",
+        # HBM bytes of the same stage per step from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; separate rocprofv3 --pmc passes)
+        "traffic": traffic,
+        "traffic_source": cnt.get("source"),
+        "traffic_over_algorithmic": (round(traffic / lm_bytes, 3) if traffic else None),
+        # the memory side of the same stage: counter bytes / stage time / peak
+        "memory_side_frac": (round(traffic / lm_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
         "algorithmic_bytes_per_launch": lm_bytes,
         "algorithmic_bytes_flat_model": b_lm_flat + 32 * args.pairs,
         "frac_flat_model": round((b_lm_flat + 32 * args.pairs) / lm_avg_s / 1e9 / HBM_PEAK_GBPS, 5),
@@ -308,12 +538,18 @@ def main():
         "whole_job_GBps": round(job_gbps, 2),
         "whole_job_frac": round(job_gbps / (HBM_PEAK_GBPS * world), 5),
         "io_only_GBps": round(b_io * world * args.steps / dt / 1e9, 2),
-        # what actually binds the stage: wave64 VALU instructions issued (SQ_INSTS_VALU of the same profile) x 2 cycles over the
-        # SIMD-cycles of the measured stage time (the instruction mix is ~40 % half-rate ops)
         "binding_resource": "VALU issue",
-        "valu_issue_frac": (round(cnt["sq_insts_valu"] * 2.0 / (N_SIMD * lm_avg_s * CLOCK_HZ), 4) if "sq_insts_valu" in cnt else None),
-        "valu_busy_frac": (round(cnt["sq_active_inst_valu"] * 4.0 / (N_SIMD * lm_avg_s * CLOCK_HZ), 4) if "sq_active_inst_valu" in cnt else None),
+        # wave64 VALU instructions issued (SQ_INSTS_VALU) x 2 cycles (the best-case issue interval, tools/ubench) over the SIMD-cycles of
+        # the stage at the device's PEAK clock (hipDeviceAttributeClockRate; a throttled clock makes the true fraction larger)
+        "shader_clock_hz_peak": clock_hz,
+        "valu_issue_frac": (round(cnt["sq_insts_valu"] * 2.0 / (N_SIMD * lm_avg_s * clock_hz), 4) if "sq_insts_valu" in cnt else None),
+        # share of the wavefronts' resident time in which a VALU instruction of theirs is executing (both counters are per-wave quad-cycle
+        # sums: a ratio of like units, <= 1 by construction — the r02 `valu_busy_frac` divided a per-wave sum by SIMD-cycles and could exceed 1)
+        "valu_active_over_wave_cycles": (round(cnt["sq_active_inst_valu"] / cnt["sq_wave_cycles"], 4)
+                                         if cnt.get("sq_wave_cycles") and "sq_active_inst_valu" in cnt else None),
     }
+    if roofline["valu_active_over_wave_cycles"] is not None:
+        assert roofline["valu_active_over_wave_cycles"] <= 1.0, roofline
     out = {
         "metric": "frame-pairs/sec (640x480, 6 pyramid levels)" if base_shape else f"frame-pairs/sec ({args.cols}x{args.rows}, {args.levels} pyramid levels)",
         "value": round(value, 2),
@@ -353,6 +589,9 @@ def main():
         "pose_err_vs_ground_truth": {"median": float(np.median(gt_err)), "max": float(gt_err.max())},
     }
 
+    parity_secondary = None
+    if world > 1:
+        out["self_check"] = multi_gpu_self_check(args, main_w, packed, gathered, rank, world)
     if rank == 0 and world == 1:
         if not args.no_secondary:
             # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload
@@ -381,6 +620,9 @@ def main():
                     "whole_job_GBps": round((io2 + lmb2) * args.steps / dt2 / 1e9, 2),
                     "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2),
                 }
+                n_par = parity_sample_sizes(args)[other]
+                if n_par > 0:
+                    parity_secondary = parity_block(args, w2, n_par)
                 del w2
             # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
             # own batch of `pairs` pairs; the GPU overlaps the latency-bound tail of one step — straggler rounds, tree descent — with the
@@ -404,8 +646,16 @@ def main():
                                             "ms_per_step": round(dt3 / args.steps * 1e3, 4),
                                             "note": "steps alternate between two batch handles on two streams; not the headline"}
             del w3
+        if not args.no_sequences and not args.no_secondary:
+            out["sequences_64"] = sequences_bench(V, args, device)
         if args.cpu_pairs != 0:
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args, main_w, value)
+            out["cpu_baseline"] = cpu_baseline(args, main_w, value)
+        n_par = parity_sample_sizes(args)[args.candidates]
+        if n_par > 0:
+            # the headline arithmetic over a FULL-SIZE sample of the batch the timed steps ran on (+ the same for the secondary workload)
+            out["parity"] = parity_block(args, main_w, n_par)
+            if parity_secondary is not None:
+                out["parity_secondary"] = parity_secondary
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -20,9 +20,21 @@ POSE_TOL = 1e-4   # rad (quaternion coordinates ~ half-angles, tighter) / metres
 SUM_RTOL = 2e-5
 
 
+ARITH = V.ARITH_EXACT
+
+
+@pytest.fixture(autouse=True, params=[V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
+def arithmetic(request):
+    """EVERY test of this file runs in both per-point arithmetics: every handle below is configured through vcfg()."""
+    global ARITH
+    ARITH = request.param
+    yield request.param
+    ARITH = V.ARITH_EXACT
+
+
 def vcfg(L, intr, mode=0, thresh=7, huber=0.0):
     return V.Config(nb_levels=L, candidates_diff_threshold=thresh, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]),
-                    candidates_mode=mode, huber_delta=huber)
+                    candidates_mode=mode, huber_delta=huber, arithmetic=ARITH)
 
 
 def to_dev(kg, kd, cg):

@@ -103,3 +103,29 @@ def test_trackers_argument_checks():
     t.track(g, d)      # no usable candidate anywhere: the pose stays the identity, like the reference
     poses, status, kf = t.current_frames()
     assert (poses == np.array([0, 0, 0, 0, 0, 0, 1], np.float32)).all()
+
+
+@pytest.mark.parametrize("arith", [V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
+def test_config3_shape_640x480_dso_sequence_of_60_frames_vs_oracle(arith):
+    """BASELINE configs[2]'s real shape: a 640x480, 6-level SEQUENCE with DSO candidate selection (every keyframe switch re-runs the
+    selector on the frame that was current, inverse_compositional.rs:224-239), 60 tracked frames, through the single-sequence C ABI
+    tracker, against the oracle Tracker frame by frame. (fr1/desk itself is not available offline: synthetic frames of the same format.)
+    The tolerance is per frame on the ACCUMULATED pose: a sequence is a chain, an alignment that lands 1e-5 away moves every later pose."""
+    rows, cols, L, n = 480, 640, 6, 61
+    intr = O.INTRINSICS_FR1
+    step = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
+    g, d = V.synth_render_frames([BLOCKY | 31337] * n, list(range(n)), [step * k for k in range(n)], rows, cols, intr)
+    gh, dh = g.cpu().numpy(), d.cpu().numpy().view(np.uint16)
+    cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=V.CANDIDATES_DSO, arithmetic=arith)
+    vt = cfg.init(0.0, dh[0], 0.0, gh[0])
+    ot = O.Tracker(O.make_config(L, intr, candidates_mode=V.CANDIDATES_DSO), 0.0, dh[0], 0.0, gh[0], keep_debug=False)
+    switches, worst = 0, 0.0
+    for k in range(1, n):
+        assert ot.track(float(k), dh[k], float(k), gh[k]) == vt.track(float(k), dh[k], float(k), gh[k])
+        e = float(np.abs(ot.current_frame()[1] - vt.current_frame()[1]).max())
+        worst = max(worst, e)
+        assert e < POSE_TOL, f"frame {k}: {e}"
+        assert ot.last()["changed_keyframe"] == bool(vt.last_stats()["change_keyframe"]), f"frame {k}"
+        switches += int(ot.last()["changed_keyframe"])
+    assert switches >= 3
+    print(f"60 frames, {switches} keyframe switches, max accumulated pose difference {worst:.2e}")

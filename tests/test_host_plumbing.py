@@ -61,10 +61,13 @@ def test_host_selftest_tracks_on_gpu():
 
 
 @pytest.mark.gpu
-def test_vors_track_cli_on_synthetic_tum_sequence(tmp_path):
-    """associations.txt + 16-bit big-endian depth PNGs + 8-bit grey PNGs -> trajectory lines, vs the oracle Tracker."""
+@pytest.mark.parametrize("arith", ["exact", "fused"])
+def test_vors_track_cli_on_synthetic_tum_sequence(tmp_path, arith):
+    """BASELINE configs[0]'s shape (TUM-format sequence, first 20 frame pairs, the reference's coarse-to-fine candidates):
+    associations.txt + 16-bit big-endian depth PNGs + 8-bit grey PNGs -> trajectory lines, vs the oracle Tracker, in both arithmetics.
+    (The real fr1/xyz is not available offline: a synthetic sequence in the same on-disk format stands in.)"""
     _ensure_host_built()
-    rows, cols, n = 480, 640, 8
+    rows, cols, n = 480, 640, 21
     intr = O.INTRINSICS_FR1
     os.makedirs(tmp_path / "depth")
     os.makedirs(tmp_path / "rgb")
@@ -79,7 +82,7 @@ def test_vors_track_cli_on_synthetic_tum_sequence(tmp_path):
         frames.append((float(f"{td:.6f}"), d, float(f"{tc:.6f}"), g))
     assoc = tmp_path / "associations.txt"
     assoc.write_text("\n".join(lines) + "\n")
-    r = subprocess.run([os.path.join(HOST, "vors_track"), "fr1", str(assoc), "--quiet"], capture_output=True, text=True)
+    r = subprocess.run([os.path.join(HOST, "vors_track"), "fr1", str(assoc), "--quiet", "--arith", arith], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     out = [l.split() for l in r.stdout.strip().splitlines()]
     assert len(out) == n - 1                                   # poses for frames 1..n-1 only (vors_track.rs:49-64)

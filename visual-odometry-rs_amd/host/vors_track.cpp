@@ -2,7 +2,9 @@
 //   Usage: ./vors_track [fr1|fr2|fr3|icl] associations_file          (vors_track.rs:24)
 // Reads a TUM RGB-D associations file, initialises the tracker with the first RGB-D frame, tracks every following frame
 // and prints one trajectory line `timestamp tx ty tz qx qy qz qw` per tracked frame on stdout (vors_track.rs:46-64).
-// Optional third argument `--quiet` silences the per-frame stderr logs (not in the reference).
+// Optional trailing flags (not in the reference): `--quiet` silences the per-frame stderr logs; `--arith exact|fused` selects the
+// per-point arithmetic (include/vors_hip.h VORS_ARITH_*, default exact); `--candidates c2f|dense|dso` the level-0 mask source
+// (default c2f = the reference's coarse-to-fine selection).
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -34,10 +36,23 @@ static std::string join(const std::string& parent, const std::string& rel) {  //
 
 int main(int argc, char** argv) {
     bool quiet = false;
-    if (argc == 4 && !std::strcmp(argv[3], "--quiet")) {
-        quiet = true;
-        argc = 3;
+    int arithmetic = VORS_ARITH_EXACT, candidates = VORS_CANDIDATES_COARSE_TO_FINE;
+    bool bad_flag = false;
+    for (int a = 3; a < argc && !bad_flag; ++a) {  // extension flags follow the reference's two positional arguments
+        const std::string flag = argv[a], val = a + 1 < argc ? argv[a + 1] : "";
+        if (flag == "--quiet") {
+            quiet = true;
+        } else if (flag == "--arith" && (val == "exact" || val == "fused")) {
+            arithmetic = val == "fused" ? VORS_ARITH_FUSED : VORS_ARITH_EXACT;
+            ++a;
+        } else if (flag == "--candidates" && (val == "c2f" || val == "dense" || val == "dso")) {
+            candidates = val == "dense" ? VORS_CANDIDATES_DENSE : (val == "dso" ? VORS_CANDIDATES_DSO : VORS_CANDIDATES_COARSE_TO_FINE);
+            ++a;
+        } else {
+            bad_flag = true;
+        }
     }
+    if (argc > 3) argc = bad_flag ? 0 : 3;
     if (argc != 3) {  // vors_track.rs:75-96
         std::fprintf(stderr, "%s\n\"Wrong number of arguments\"\n", USAGE);
         return 0;  // the reference's main() only prints the error (vors_track.rs:17-22)
@@ -75,6 +90,8 @@ int main(int argc, char** argv) {
         };
         // vors_track.rs:34-40
         track::Config config{6, 7, tum_rgbd::DEPTH_SCALE, intrinsics, 0.0001f};
+        config.arithmetic = arithmetic;
+        config.candidates_mode = candidates;
         std::vector<uint16_t> depth;
         std::vector<uint8_t> gray;
         uint32_t w = 0, h = 0;
