@@ -93,6 +93,8 @@ typedef struct vors_pair_stats {
 const char* vors_last_error(void);
 /* Number of visible HIP devices (0 when none / no runtime). Never fails. */
 int vors_device_count(void);
+/* Peak shader clock (hipDeviceAttributeClockRate, kHz), compute units and device memory of a HIP device (all nullable). */
+vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes);
 /* ABI version of this header: bump on any signature change. */
 int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level
                               * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version */

@@ -364,6 +364,20 @@ def track_pairs(cfg, kf_gray, kf_depth, cur_gray, cur_depth=None, init_poses7=No
     return dict(poses=poses, models=models, status=status, nb_iter=nb_iter, n_points=n_points, flow=flow)
 
 
+def track_sequences(cfg, gray, depth, n_threads=1, variant=None):
+    """n_seq independent sequences, one Tracker each (vors_track.rs:46-62 per sequence). gray / depth: [n_frames, n_seq, rows, cols]
+    (frame-major, as a lock-step host holds them). -> poses [n_seq, n_frames-1, 7], status, changed_keyframe [n_seq, n_frames-1]."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    depth = np.ascontiguousarray(depth, np.uint16)
+    F, n, rows, cols = gray.shape
+    poses = np.zeros((n, F - 1, 7), np.float32)
+    status = np.zeros((n, F - 1), np.int32)
+    switch = np.zeros((n, F - 1), np.int32)
+    (variant_lib(variant) if variant else lib()).vo_track_sequences(C.byref(cfg), n, F, _u8(gray), _u16(depth), rows, cols, _f32(poses), _i32(status),
+                                                                     _i32(switch), n_threads)
+    return dict(poses=poses, status=status, changed_keyframe=switch)
+
+
 def mean_pyramid(img, max_levels):
     img = np.ascontiguousarray(img, np.uint8)
     rows, cols = img.shape

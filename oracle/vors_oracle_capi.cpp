@@ -263,6 +263,48 @@ int vo_track_pairs(const vo_config* cfg, int n_pairs, const uint8_t* kf_gray, co
     return 0;
 }
 
+// n_seq independent SEQUENCES of n_frames frames each, one Tracker per sequence (vors_track.rs:46-62 for each): frame k of sequence s
+// at ((size_t)k * n_seq + s) * rows * cols (frame-major, the layout a lock-step host holds). Frame 0 initialises, frames 1 .. n_frames-1
+// are tracked with depth timestamp = k. out_poses7 [n_seq][n_frames-1][7], out_status / out_switch [n_seq][n_frames-1].
+int vo_track_sequences(const vo_config* cfg, int n_seq, int n_frames, const uint8_t* gray, const uint16_t* depth, int rows, int cols,
+                       float* out_poses7, int32_t* out_status, int32_t* out_switch, int n_threads) {
+    const track::Config config = to_config(cfg);
+    const size_t S = (size_t)rows * cols;
+    auto work = [&](int lo, int hi) {
+        for (int s = lo; s < hi; ++s) {
+            track::Tracker t;
+            auto d = DMatrix<uint16_t>::from_row_slice(rows, cols, depth + (size_t)s * S);
+            auto g = DMatrix<uint8_t>::from_row_slice(rows, cols, gray + (size_t)s * S);
+            const bool ok = track::Tracker::init(config, 0.0, d, 0.0, std::move(g), false, t);
+            for (int k = 1; k < n_frames; ++k) {
+                const size_t o = (size_t)s * (n_frames - 1) + (k - 1);
+                if (!ok) {
+                    out_status[o] = -1;
+                    continue;
+                }
+                const size_t f = ((size_t)k * n_seq + s) * S;
+                auto dk = DMatrix<uint16_t>::from_row_slice(rows, cols, depth + f);
+                auto gk = DMatrix<uint8_t>::from_row_slice(rows, cols, gray + f);
+                out_status[o] = t.track((double)k, dk, (double)k, std::move(gk));
+                pose_to7(t.current_frame_pose, out_poses7 + 7 * o);
+                out_switch[o] = t.last_changed_keyframe ? 1 : 0;
+            }
+        }
+    };
+    if (n_threads <= 1) {
+        work(0, n_seq);
+    } else {
+        std::vector<std::thread> th;
+        const int per = (n_seq + n_threads - 1) / n_threads;
+        for (int k = 0; k < n_threads; ++k) {
+            const int lo = k * per, hi = std::min(n_seq, lo + per);
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        for (auto& x : th) x.join();
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------ stand-alone stages and KAT helpers
 // mean_pyramid (multires.rs:21-31): writes levels concatenated row-major; returns the number of levels.
 int vo_mean_pyramid(const uint8_t* img, int rows, int cols, int max_levels, uint8_t* out, int32_t* out_rows, int32_t* out_cols) {

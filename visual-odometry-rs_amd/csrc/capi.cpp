@@ -237,6 +237,27 @@ int vors_device_count(void) {
 }
 int vors_abi_version(void) { return 3; }
 
+vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes) {
+    vors_status st = require_device();
+    if (st != VORS_OK) return st;
+    if (device < 0 || device >= vors_device_count()) return fail(VORS_ERR_INVALID_ARGUMENT, "device index out of range");
+    int v = 0;
+    if (clock_khz) {
+        HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, device));
+        *clock_khz = v;
+    }
+    if (compute_units) {
+        HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
+        *compute_units = v;
+    }
+    if (memory_bytes) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        *memory_bytes = (uint64_t)prop.totalGlobalMem;
+    }
+    return VORS_OK;
+}
+
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {

@@ -90,7 +90,7 @@ class vors_obs(C.Structure):
 
 # every symbol include/vors_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    "vors_last_error", "vors_device_count", "vors_abi_version",
+    "vors_last_error", "vors_device_count", "vors_device_info", "vors_abi_version",
     "vors_tracker_create", "vors_tracker_track", "vors_tracker_current_frame", "vors_tracker_last_stats",
     "vors_tracker_keyframe", "vors_tracker_destroy",
     "vors_track_pairs",
@@ -191,6 +191,14 @@ def _check(st):
 
 def device_count():
     return lib().vors_device_count()
+
+
+def device_info(device=0):
+    """-> dict(clock_khz = peak shader clock, compute_units, memory_bytes) of a HIP device."""
+    clk, cu, mem = C.c_int(), C.c_int(), C.c_uint64()
+    lib().vors_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    _check(lib().vors_device_info(int(device), C.byref(clk), C.byref(cu), C.byref(mem)))
+    return dict(clock_khz=clk.value, compute_units=cu.value, memory_bytes=mem.value)
 
 
 def _ptr(a):
