@@ -9,9 +9,11 @@ from oracle import oracle as O
 n=120; rows, cols, L = 480, 640, 6
 intr = O.INTRINSICS_FR1
 step = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
-frames = [O.synth_frame(31337, step * k, rows, cols, intr, frame_salt=k, n_threads=8) for k in range(n)]
+frames_smooth = [O.synth_frame(31337, step * k, rows, cols, intr, frame_salt=k, n_threads=8) for k in range(n)]
+frames_blocky = [O.synth_frame((1 << 63) | 31337, step * k, rows, cols, intr, frame_salt=k, n_threads=8) for k in range(n)]
 for rep in range(3):
-  for mode in (0, 1):
+  for mode in (0, 1, 2):
+    frames = frames_blocky if mode == 2 else frames_smooth
     for arith in (1, 0):
         cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=mode, arithmetic=arith)
         vt = cfg.init(0.0, frames[0][1], 0.0, frames[0][0])

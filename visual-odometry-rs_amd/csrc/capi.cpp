@@ -481,24 +481,6 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     return VORS_OK;
 }
 
-// Tracker use: the current frame becomes the keyframe (inverse_compositional.rs:227-239): its pyramid is reused
-// (no recomputation, like the reference's move of img_multires) and only precompute_multires_data runs.
-static vors_status batch_promote_current(vors_batch* b, int n_pairs, const uint16_t* d_depth, hipStream_t s) {
-    std::swap(b->kf_upper, b->cur_upper);
-    b->kf_level0 = b->cur_level0;
-    b->kf_depth = d_depth;
-    Pyramid kf{b->kf_level0, b->kf_upper};
-    STAGE_BEGIN(b, 1, s);
-    if (b->g.mode == VORS_CANDIDATES_DSO) {
-        launch_keyframe_dso(b->g, kf, d_depth, b->dso, b->mask0, b->pp, b->rec, n_pairs, s);
-    } else {
-        launch_keyframe(b->g, kf, d_depth, b->rec, n_pairs, s);
-    }
-    STAGE_END(b, 1, s);
-    HIP_TRY(hipGetLastError());
-    return VORS_OK;
-}
-
 static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
                                        const float* d_kf_poses7, float* d_out_poses7, int32_t* d_out_status,
                                        vors_pair_stats* d_out_stats, hipStream_t s) {
@@ -741,22 +723,68 @@ vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t*
 // ---------------------------------------------------------------------------------------------------------------
 // Tracker: one sequence (Config::init / Tracker::track / Tracker::current_frame)
 // ---------------------------------------------------------------------------------------------------------------
+// The single sequence is the N = 1 case of the lock-step engine below (vors_trackers_*): poses, the keyframe test and the promotion of
+// the current frame stay on the device, so a frame is ONE chain of stream-ordered work and ONE synchronisation — upload (pinned staging,
+// the depth map on a second stream: it is only read by a promotion, after the LM stage), Tracker::track, read-back of pose / status /
+// diagnostics. The host mirrors only what current_frame() / keyframe() report.
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault); }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
 struct vors_tracker {
     vors_config cfg;
-    int rows = 0, cols = 0, layout = 0;
-    vors_batch* batch = nullptr;
-    DevBuf gray[2];  // [kf_slot] = keyframe level 0, [1 - kf_slot] = current level 0
-    int kf_slot = 0;
-    DevBuf depth, tmp, poses /* prev(7) kf(7) out(7) */, status, stats;
-    // State of inverse_compositional.rs:52-60
+    int rows = 0, cols = 0, layout = 0, device = 0;
+    vors_trackers* seq = nullptr;  // n_sequences = 1
+    DevBuf gray, depth, tmp8, tmp16;   // the frame on the device (row-major); tmp*: column-major uploads before the transpose
+    PinnedBuf h_gray, h_depth, h_out;  // staging: frame in; pose7 + status + keyframe index + vors_pair_stats out
+    hipStream_t s_main = nullptr, s_copy = nullptr;
+    hipEvent_t ev_depth = nullptr, ev_frame_done = nullptr;
+    // State of inverse_compositional.rs:52-60 as the host reports it
     double keyframe_depth_timestamp = 0, keyframe_img_timestamp = 0;
     Iso keyframe_pose = iso_identity();
     double current_frame_depth_timestamp = 0, current_frame_img_timestamp = 0;
     Iso current_frame_pose = iso_identity();
     vors_pair_stats last{};
     bool has_last = false;
-    ~vors_tracker() { vors_batch_destroy(batch); }
+    ~vors_tracker() {
+        vors_trackers_destroy(seq);
+        if (ev_depth) (void)hipEventDestroy(ev_depth);
+        if (ev_frame_done) (void)hipEventDestroy(ev_frame_done);
+        if (s_main) (void)hipStreamDestroy(s_main);
+        if (s_copy) (void)hipStreamDestroy(s_copy);
+    }
 };
+struct TrackerOut {  // layout of vors_tracker::h_out
+    float pose[7];
+    int32_t status, kf_index;
+    vors_pair_stats stats;
+};
+
+// Frame -> device (row-major). The caller's buffers are pageable: they are copied into pinned staging first, so that the transfers are
+// truly asynchronous (the depth map travels on its own stream under the LM stage).
+static vors_status tracker_upload(vors_tracker* t, const uint8_t* gray, const uint16_t* depth) {
+    const size_t S = (size_t)t->rows * t->cols;
+    std::memcpy(t->h_gray.p, gray, S);
+    std::memcpy(t->h_depth.p, depth, S * 2);
+    // the previous frame's promotion may still read t->depth: the copy stream first waits for the end of the previous frame
+    HIP_TRY(hipStreamWaitEvent(t->s_copy, t->ev_frame_done, 0));
+    if (t->layout == VORS_ROW_MAJOR) {
+        HIP_TRY(hipMemcpyAsync(t->gray.p, t->h_gray.p, S, hipMemcpyHostToDevice, t->s_main));
+        HIP_TRY(hipMemcpyAsync(t->depth.p, t->h_depth.p, S * 2, hipMemcpyHostToDevice, t->s_copy));
+    } else {
+        HIP_TRY(hipMemcpyAsync(t->tmp8.p, t->h_gray.p, S, hipMemcpyHostToDevice, t->s_main));
+        launch_transpose_u8(t->tmp8.as<uint8_t>(), t->gray.as<uint8_t>(), t->rows, t->cols, 1, t->s_main);
+        HIP_TRY(hipMemcpyAsync(t->tmp16.p, t->h_depth.p, S * 2, hipMemcpyHostToDevice, t->s_copy));
+        launch_transpose_u16(t->tmp16.as<uint16_t>(), t->depth.as<uint16_t>(), t->rows, t->cols, 1, t->s_copy);
+    }
+    HIP_TRY(hipEventRecord(t->ev_depth, t->s_copy));
+    return VORS_OK;
+}
 
 extern "C" {
 
@@ -766,11 +794,11 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
     *out = nullptr;
     if (!depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL image pointer");
     if (layout != VORS_ROW_MAJOR && layout != VORS_COL_MAJOR) return fail(VORS_ERR_INVALID_ARGUMENT, "bad layout");
-    vors_batch* b = nullptr;
-    vors_status st = vors_batch_create(cfg, 1, rows, cols, &b);
+    vors_trackers* seq = nullptr;
+    vors_status st = vors_trackers_create(cfg, 1, rows, cols, &seq);
     if (st != VORS_OK) return st;
     vors_tracker* t = new vors_tracker();
-    t->batch = b;
+    t->seq = seq;
     t->cfg = *cfg;
     t->rows = rows;
     t->cols = cols;
@@ -779,21 +807,27 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
         vors_tracker* t;
         ~Guard() { delete t; }
     } guard{t};
+    if (hipGetDevice(&t->device) != hipSuccess) t->device = 0;  // the tracker lives on the device that is current at creation
     const size_t S = (size_t)rows * cols;
-    HIP_TRY(t->gray[0].alloc(S));
-    HIP_TRY(t->gray[1].alloc(S));
+    HIP_TRY(t->gray.alloc(S));
     HIP_TRY(t->depth.alloc(S * 2));
-    HIP_TRY(t->tmp.alloc(S * 2));
-    HIP_TRY(t->poses.alloc(21 * sizeof(float)));
-    HIP_TRY(t->status.alloc(sizeof(int32_t)));
-    HIP_TRY(t->stats.alloc(sizeof(vors_pair_stats)));
-    hipStream_t s = nullptr;
-    if ((st = upload_u8(gray, 1, rows, cols, layout, t->gray[0], t->tmp, s)) != VORS_OK) return st;
-    if ((st = upload_u16(depth, 1, rows, cols, layout, t->depth, t->tmp, s)) != VORS_OK) return st;
-    st = vors_batch_prepare_keyframes(b, 1, t->gray[0].as<uint8_t>(), t->depth.as<uint16_t>(), s);
+    if (layout == VORS_COL_MAJOR) {
+        HIP_TRY(t->tmp8.alloc(S));
+        HIP_TRY(t->tmp16.alloc(S * 2));
+    }
+    HIP_TRY(t->h_gray.alloc(S));
+    HIP_TRY(t->h_depth.alloc(S * 2));
+    HIP_TRY(t->h_out.alloc(sizeof(TrackerOut)));
+    HIP_TRY(hipStreamCreateWithFlags(&t->s_main, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&t->s_copy, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_depth, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_frame_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
+    if ((st = tracker_upload(t, gray, depth)) != VORS_OK) return st;
+    HIP_TRY(hipStreamWaitEvent(t->s_main, t->ev_depth, 0));
+    st = vors_trackers_init(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->s_main);  // (synchronises s_main)
     if (st != VORS_OK) return st;
-    HIP_TRY(hipStreamSynchronize(s));
-    t->kf_slot = 0;
+    HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
     t->keyframe_depth_timestamp = depth_time;
     t->keyframe_img_timestamp = img_time;
     t->current_frame_depth_timestamp = depth_time;
@@ -803,46 +837,44 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
     return VORS_OK;
 }
 
+// The heart of vors_trackers_track for ONE sequence whose depth map arrives on another stream (defined with the lock-step engine).
+vors_status vors_trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
+                                            hipStream_t s);
+
 vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
                                int* track_status) {
     if (!t || !depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
-    DeviceGuard guard(t->batch->device);  // the tracker lives on the device that was current at creation
-    hipStream_t s = nullptr;
-    const int cur_slot = 1 - t->kf_slot;
-    vors_status st = upload_u8(gray, 1, t->rows, t->cols, t->layout, t->gray[cur_slot], t->tmp, s);
+    DeviceGuard guard(t->device);
+    vors_status st = tracker_upload(t, gray, depth);
     if (st != VORS_OK) return st;
-    float h_poses[14];
-    iso_store(t->current_frame_pose, h_poses);
-    iso_store(t->keyframe_pose, h_poses + 7);
-    HIP_TRY(hipMemcpyAsync(t->poses.p, h_poses, sizeof(h_poses), hipMemcpyHostToDevice, s));
-    float* dp = t->poses.as<float>();
-    st = batch_track_current(t->batch, 1, t->gray[cur_slot].as<uint8_t>(), dp, dp + 7, dp + 14, t->status.as<int32_t>(),
-                             t->stats.as<vors_pair_stats>(), s);
+    // Tracker::track (inverse_compositional.rs:170-240) incl. the keyframe switch, all on the device; the promotion (the only reader of
+    // the depth map) waits for its upload
+    st = vors_trackers_track_depth_event(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main);
     if (st != VORS_OK) return st;
-    float h_out[7];
-    int32_t h_status = 0;
-    HIP_TRY(hipMemcpyAsync(h_out, dp + 14, sizeof(h_out), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&h_status, t->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&t->last, t->stats.p, sizeof(vors_pair_stats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
+    const float* d_pose = nullptr;
+    const int32_t *d_status = nullptr, *d_kf = nullptr;
+    const vors_pair_stats* d_stats = nullptr;
+    (void)vors_trackers_state(t->seq, &d_pose, nullptr, &d_status, &d_kf, &d_stats);
+    TrackerOut* o = t->h_out.as<TrackerOut>();
+    HIP_TRY(hipMemcpyAsync(o->pose, d_pose, sizeof(o->pose), hipMemcpyDeviceToHost, t->s_main));
+    HIP_TRY(hipMemcpyAsync(&o->status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, t->s_main));
+    HIP_TRY(hipMemcpyAsync(&o->kf_index, d_kf, sizeof(int32_t), hipMemcpyDeviceToHost, t->s_main));
+    HIP_TRY(hipMemcpyAsync(&o->stats, d_stats, sizeof(vors_pair_stats), hipMemcpyDeviceToHost, t->s_main));
+    HIP_TRY(hipStreamSynchronize(t->s_main));
+    t->last = o->stats;
     t->has_last = true;
     // inverse_compositional.rs:203-208
     t->current_frame_depth_timestamp = depth_time;
     t->current_frame_img_timestamp = img_time;
-    t->current_frame_pose = iso_load(h_out);  // == previous pose when the optimizer failed
-    // inverse_compositional.rs:224-239
+    t->current_frame_pose = iso_load(o->pose);  // == previous pose when the optimizer failed
+    // inverse_compositional.rs:224-239 (the device has already promoted the frame)
     if (t->last.change_keyframe) {
-        st = upload_u16(depth, 1, t->rows, t->cols, t->layout, t->depth, t->tmp, s);
-        if (st != VORS_OK) return st;
-        st = batch_promote_current(t->batch, 1, t->depth.as<uint16_t>(), s);
-        if (st != VORS_OK) return st;
-        HIP_TRY(hipStreamSynchronize(s));
-        t->kf_slot = cur_slot;
         t->keyframe_depth_timestamp = depth_time;
         t->keyframe_img_timestamp = img_time;
         t->keyframe_pose = t->current_frame_pose;
     }
-    if (track_status) *track_status = h_status;
+    if (track_status) *track_status = o->status;
     return VORS_OK;
 }
 
@@ -866,7 +898,9 @@ vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stat
 }
 void vors_tracker_destroy(vors_tracker* t) {
     if (!t) return;
-    DeviceGuard guard(t->batch ? t->batch->device : 0);  // the buffers are freed on the device they live on
+    DeviceGuard guard(t->device);  // the buffers are freed on the device they live on
+    if (t->s_main) (void)hipStreamSynchronize(t->s_main);
+    if (t->s_copy) (void)hipStreamSynchronize(t->s_copy);
     delete t;
 }
 
@@ -961,10 +995,16 @@ vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const ui
 }
 
 vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream) {
+    return vors_trackers_track_depth_event(t, d_gray, d_depth, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+// depth_ready (nullable): an event after which d_depth holds this frame's depth map (uploaded on another stream); it is waited for just
+// before the promotion, the only reader of the depth map.
+vors_status vors_trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
+                                            hipStream_t s) {
     if (!t || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!t->initialised) return fail(VORS_ERR_INVALID_ARGUMENT, "vors_trackers_track called before vors_trackers_init");
     vors_batch* b = t->batch;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
     DeviceGuard guard(b->device);
     vors_status st = check_stream(b, s);
     if (st != VORS_OK) return st;
@@ -982,6 +1022,7 @@ vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const u
     Geom gm = b->g;
     gm.sel_list = t->promo_list.as<int>();
     gm.sel_count = t->promo_count.as<int>();
+    if (depth_ready) HIP_TRY(hipStreamWaitEvent(s, depth_ready, 0));
     STAGE_BEGIN(b, 1, s);
     if (b->g.mode == VORS_CANDIDATES_DENSE) {
         const size_t S = (size_t)b->g.S0;
