@@ -112,6 +112,10 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
 /* Returns VORS_OK and writes the VORS_TRACK_* status of this frame to *track_status (nullable). */
 vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time,
                                const uint8_t* gray, int* track_status);
+/* Same with the frame's shape stated: fails with VORS_ERR_INVALID_ARGUMENT when rows x cols differ from the shape the tracker was created
+ * with (vors_tracker_track trusts the caller's buffers to hold rows * cols elements, like the reference trusts its DMatrix arguments). */
+vors_status vors_tracker_track_checked(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
+                                       int rows, int cols, int* track_status);
 vors_status vors_tracker_current_frame(const vors_tracker* t, double* timestamp, float pose7[7]);
 /* Diagnostics of the last track() and keyframe pose (not in the reference API). */
 vors_status vors_tracker_last_stats(const vors_tracker* t, vors_pair_stats* stats);

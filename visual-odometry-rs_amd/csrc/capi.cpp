@@ -878,6 +878,15 @@ vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_
     return VORS_OK;
 }
 
+vors_status vors_tracker_track_checked(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
+                                       int rows, int cols, int* track_status) {
+    if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (rows != t->rows || cols != t->cols)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "frame is " + std::to_string(rows) + " x " + std::to_string(cols) + " but the tracker was created for " +
+                                                   std::to_string(t->rows) + " x " + std::to_string(t->cols));
+    return vors_tracker_track(t, depth_time, depth, img_time, gray, track_status);
+}
+
 vors_status vors_tracker_current_frame(const vors_tracker* t, double* timestamp, float pose7[7]) {
     if (!t || !timestamp || !pose7) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     *timestamp = t->current_frame_depth_timestamp;  // the DEPTH timestamp: inverse_compositional.rs:243-247

@@ -93,7 +93,7 @@ class Tracker {  // inverse_compositional.rs:31-34
             throw std::invalid_argument("Tracker::track: frame shape differs from the keyframe's");
         if (depth_map.layout != layout_ || img.layout != layout_) throw std::invalid_argument("Tracker::track: layout differs from init's");
         int status = 0;
-        check(vors_tracker_track(h_, depth_time, depth_map.data, img_time, img.data, &status));
+        check(vors_tracker_track_checked(h_, depth_time, depth_map.data, img_time, img.data, img.rows, img.cols, &status));
         vors_pair_stats s;
         check(vors_tracker_last_stats(h_, &s));
         last_ = s;

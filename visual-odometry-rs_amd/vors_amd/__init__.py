@@ -91,7 +91,7 @@ class vors_obs(C.Structure):
 # every symbol include/vors_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "vors_last_error", "vors_device_count", "vors_device_info", "vors_abi_version",
-    "vors_tracker_create", "vors_tracker_track", "vors_tracker_current_frame", "vors_tracker_last_stats",
+    "vors_tracker_create", "vors_tracker_track", "vors_tracker_track_checked", "vors_tracker_current_frame", "vors_tracker_last_stats",
     "vors_tracker_keyframe", "vors_tracker_destroy",
     "vors_track_pairs",
     "vors_batch_create", "vors_batch_create_on", "vors_batch_device", "vors_batch_track_pairs", "vors_batch_prepare_keyframes", "vors_batch_track_current",
@@ -130,6 +130,7 @@ def lib():
         vp, i, d, f = C.c_void_p, C.c_int, C.c_double, C.c_float
         _lib.vors_tracker_create.argtypes = [C.POINTER(vors_config), d, vp, d, vp, i, i, i, C.POINTER(vp)]
         _lib.vors_tracker_track.argtypes = [vp, d, vp, d, vp, C.POINTER(i)]
+        _lib.vors_tracker_track_checked.argtypes = [vp, d, vp, d, vp, i, i, C.POINTER(i)]
         _lib.vors_tracker_current_frame.argtypes = [vp, C.POINTER(d), vp]
         _lib.vors_tracker_keyframe.argtypes = [vp, C.POINTER(d), vp]
         _lib.vors_tracker_last_stats.argtypes = [vp, C.POINTER(vors_pair_stats)]
@@ -289,7 +290,8 @@ class Tracker:
             raise VorsError(f"Tracker.track: frame shape {img.shape} / depth shape {depth_map.shape} differ from the {want} "
                             "this tracker was created with")
         st = C.c_int()
-        _check(lib().vors_tracker_track(self._h, depth_time, _ptr(depth_map), img_time, _ptr(img), C.byref(st)))
+        rows, cols = img.shape if self._layout == ROW_MAJOR else img.shape[::-1]
+        _check(lib().vors_tracker_track_checked(self._h, depth_time, _ptr(depth_map), img_time, _ptr(img), rows, cols, C.byref(st)))
         return st.value
 
     def current_frame(self):
