@@ -3,7 +3,8 @@
 # Pass 1: --kernel-trace --stats (per-kernel durations). Passes 2,3: PMC FETCH_SIZE / WRITE_SIZE, each in its own
 # run with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: not in one pass).
 TAG=${1:-r01}; shift
-ARGS=${@:-"--steps 5 --warmup 2 --no-secondary --cpu-pairs 0"}   # (always pass --no-secondary --cpu-pairs 0: one workload per profile)
+ARGS=${@:-"--steps 5 --warmup 2"}
+ARGS="$ARGS --no-secondary --cpu-pairs 0 --parity-pairs 0 --no-pmc --no-sequences"   # one workload per profile, nothing but the timed steps
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
