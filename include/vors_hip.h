@@ -184,7 +184,11 @@ typedef struct vors_batch vors_batch;
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
  *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical)
  *   VORS_DSO_PLANES=1            DSO mode: keyframe records through per-level inverse-depth planes instead of the sorted pick list
- *                                (same candidates and values; the lists then come out in raster instead of Morton order) */
+ *                                (same candidates and values; the lists then come out in raster instead of Morton order)
+ *   VORS_DSO_SCAN=1              DSO mode: the usable picks from a pass over the stamp plane instead of the selection rounds' own list
+ *                                (identical lists)
+ *   VORS_FUSED_EXACT_POINTS=n    FUSED arithmetic: levels of at most n points are evaluated in the EXACT arithmetic (default 2500; 0 = the
+ *                                round-2 behaviour, which leaves ~0.2 % of coarse-to-fine pairs beyond 1e-4: DESIGN.md §4) */
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
 /* Same on an explicit HIP device (vors_batch_create = the calling thread's current device). The handle remembers its device: every
  * entry point switches to it for the call and restores the caller's current device; a hip_stream of another device is rejected with

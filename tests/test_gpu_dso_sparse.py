@@ -36,10 +36,11 @@ np.savez(out, **res)
 """
 
 
-def run(tmp_path, tag, planes, rows, cols, L):
+def run(tmp_path, tag, planes, rows, cols, L, scan=False):
     out = str(tmp_path / f"{tag}.npz")
     env = dict(os.environ)
     env["VORS_DSO_PLANES"] = "1" if planes else "0"
+    env["VORS_DSO_SCAN"] = "1" if scan else "0"
     subprocess.run([sys.executable, "-c", DUMP.format(root=ROOT, rows=rows, cols=cols, L=L, out=out)], check=True, env=env, timeout=300)
     return np.load(out)
 
@@ -58,3 +59,13 @@ def test_sparse_form_equals_plane_path(tmp_path, rows, cols, L):
     print(f"[{cols}x{rows} L{L}] level-0 candidates per pair {n_lvl0}; max pose difference between the two list orders "
           f"{np.abs(a['poses'] - b['poses']).max():.2e}")
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-4  # same candidates, different order of summation
+
+
+@pytest.mark.parametrize("rows,cols,L", [(480, 640, 6), (121, 163, 4), (96, 128, 3), (64, 96, 2)])
+def test_pick_list_of_the_selection_rounds_equals_the_scan_of_the_stamp_plane(tmp_path, rows, cols, L):
+    """Round 3: dso_rounds_kernel hands the picks of its final round over as a list (no pass over the 1-byte-per-pixel stamp plane);
+    VORS_DSO_SCAN=1 still extracts them with mask_sparse_scan_kernel. Both feed the same sort: identical lists, hence identical POSES
+    bit for bit (incl. the shape whose list overflows and goes through in groups of bands)."""
+    a, b = run(tmp_path, "list", False, rows, cols, L), run(tmp_path, "scan", False, rows, cols, L, scan=True)
+    for key in a.files:
+        assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key

@@ -173,7 +173,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.IZ) (void)hipFree(b->rec.IZ);
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
-    void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state,
+    void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state, b->dso.pick_list,
                      b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used, b->rec.S, b->rec.stage, b->rec.region_cnt,
                      b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
     for (void* p : extra)
@@ -339,6 +339,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->dso.mask1, np * b->dso.mask_stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.picked, np * g.S0, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.state, np, &b->bytes);
+        // picks of one selection round: every block of the first round's three levels at most (a later round with smaller blocks may
+        // exceed it: the list then overflows and the pair falls back to the scan of the stamp plane)
+        b->dso.list_cap = (g.S0 / 16 + g.S0 / 64 + g.S0 / 256 + 1024 + 3) & ~3;
+        if (e == hipSuccess) e = dmalloc(&b->dso.pick_list, np * (size_t)b->dso.list_cap, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->mask0, np * g.S0, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.iz, np * b->pp.stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->pp.v, np * b->pp.stride, &b->bytes);

@@ -32,6 +32,15 @@ __device__ __forceinline__ uint64_t dso_splitmix64(uint64_t x) {
 // (sqrt(((gx^2 + gy^2) / 4) as u16 as f32)) as u16, border 0 (gradient.rs:49-65, candidates_dso.rs:42), written to the gmag plane, and
 // the region median sorted[len / 2] through a wave-private 256-bin histogram in LDS (dso.rs:307-325). Also clears the pick stamps of the
 // previous keyframe. A lane owns 4 consecutive pixels in each of 4 rows (row = lane / 8 + 8 * pass).
+// floor(sqrt(n)) for 0 <= n < 2^22, exactly: the hardware square root (1 ulp) truncated, then corrected by at most one. Equals
+// (sqrtf((float)n) as u16) of gradient.rs:49-65 — the correctly rounded root of an integer below 2^22 never rounds up to the next integer
+// (k - sqrt(k^2 - 1) > 1 / (2k) >> half an ulp of k).
+__device__ __forceinline__ int isqrt_floor(int n) {
+    int s = (int)__builtin_amdgcn_sqrtf((float)n);
+    s -= (s * s > n) ? 1 : 0;
+    s += ((s + 1) * (s + 1) <= n) ? 1 : 0;
+    return s;
+}
 __device__ __forceinline__ void dso_hist_add(int* hist, int v, bool active) {
     // most of a region usually shares one value (flat image areas): the first active lane's value is added once for the whole
     // wavefront, the remaining lanes fall back to LDS atomics
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
             for (int k = 0; k < 4; ++k) {
                 const int gx = row[k + 2] - row[k], gy = (int)((dn[ps] >> (8 * k)) & 0xff) - (int)((up[ps] >> (8 * k)) & 0xff);
                 const int x = x0 + k;
-                out[ps][k] = (in && x > 0 && x < cols - 1) ? (int)sqrtf((float)((gx * gx + gy * gy) / 4)) : 0;  // <= 180
+                out[ps][k] = (in && x > 0 && x < cols - 1) ? isqrt_floor((gx * gx + gy * gy) / 4) : 0;  // <= 180
             }
             if (own) {
                 const size_t o = (size_t)y * cols + x0;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
                     if (x > 0 && y > 0 && x < cols - 1 && y < rows - 1) {
                         const uint8_t* p = img + o;
                         const int gx = (int)p[1] - (int)p[-1], gy = (int)p[cols] - (int)p[-cols];
-                        v = (int)sqrtf((float)((gx * gx + gy * gy) / 4));
+                        v = isqrt_floor((gx * gx + gy * gy) / 4);
                     }
                     gm[o] = (uint8_t)v;
                     pk[o] = 0;
@@ -140,6 +149,99 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
     }
 }
 
+// The same for a STRIP of four horizontally adjacent regions per workgroup (128 pixels x 32 rows), when cols % 16 == 0 and the planes are
+// 16-byte aligned: a thread owns 16 consecutive pixels of ONE row (wavefront w: rows 8 w .. 8 w + 7 of the strip, 8 lanes per row), so every
+// load / store instruction of a wavefront moves eight full 128-byte lines instead of eight quarter lines (the per-region form above spends
+// 1.2 of its 1.57 ms per 4096 pairs on its 20 narrow loads per lane). The four region histograms are shared by the workgroup: a thread
+// adds its 16 values run by run (flat areas: one LDS atomic per thread); then wavefront w extracts the median of region w.
+__global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws) {
+    __shared__ int s_hist[4][256];
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+    const int rc = (cols + DSO_REGION - 1) / DSO_REGION, strips = (cols + 127) / 128;
+    const int ri = blockIdx.x / strips, sj = blockIdx.x - ri * strips;
+    *reinterpret_cast<int4*>(&s_hist[0][0] + 4 * tid) = make_int4(0, 0, 0, 0);
+    const uint8_t* img = kf0 + (size_t)pair * g.S0;
+    uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
+    uint8_t* pk = ws.picked + (size_t)pair * g.S0;
+    const int x0 = sj * 128 + (lane & 7) * 16, y = ri * DSO_REGION + wave * 8 + (lane >> 3);
+    const bool own = x0 < cols && y < rows;  // (cols % 16 == 0: a thread's 16 pixels are all inside or all outside)
+    const int reg = (lane & 7) >> 1;         // region of the strip this thread's pixels belong to
+    int out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    if (own) {
+        const size_t o = (size_t)y * cols + x0;
+        const bool yin = y > 0 && y < rows - 1;
+        if (yin) {
+            const uint4 up = *reinterpret_cast<const uint4*>(img + o - cols), md = *reinterpret_cast<const uint4*>(img + o),
+                        dn = *reinterpret_cast<const uint4*>(img + o + cols);
+            const int left = x0 > 0 ? img[o - 1] : 0, right = x0 + 16 < cols ? img[o + 16] : 0;
+            const uint32_t u[4] = {up.x, up.y, up.z, up.w}, m[4] = {md.x, md.y, md.z, md.w}, d[4] = {dn.x, dn.y, dn.z, dn.w};
+            int row[18];
+            row[0] = left;
+            row[17] = right;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) row[k + 1] = (int)((m[k >> 2] >> (8 * (k & 3))) & 0xff);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int gx = row[k + 2] - row[k];
+                const int gy = (int)((d[k >> 2] >> (8 * (k & 3))) & 0xff) - (int)((u[k >> 2] >> (8 * (k & 3))) & 0xff);
+                const int x = x0 + k;
+                out[k] = (x > 0 && x < cols - 1) ? isqrt_floor((gx * gx + gy * gy) / 4) : 0;  // <= 180
+            }
+        }
+        uint32_t w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            w4[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) | ((uint32_t)out[4 * q + 3] << 24);
+        *reinterpret_cast<uint4*>(gm + o) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        *reinterpret_cast<uint4*>(pk + o) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (own) {  // the thread's 16 values into its region's histogram, run by run
+        int* hist = s_hist[reg];
+        int cur = out[0], cnt = 1;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            if (out[k] == cur) {
+                ++cnt;
+            } else {
+                atomicAdd(&hist[cur], cnt);
+                cur = out[k];
+                cnt = 1;
+            }
+        }
+        atomicAdd(&hist[cur], cnt);
+    }
+    __syncthreads();
+    // wavefront w: the median of region w of the strip = first bin whose inclusive prefix count exceeds len / 2
+    const int rj = sj * 4 + wave;
+    if (rj >= rc) return;
+    const int h = min(DSO_REGION, rows - ri * DSO_REGION), w = min(DSO_REGION, cols - rj * DSO_REGION);
+    const int4 b = *reinterpret_cast<const int4*>(&s_hist[wave][4 * lane]);
+    const int mine = b.x + b.y + b.z + b.w;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int kmed = (h * w) / 2;
+    if (incl > kmed && incl - mine <= kmed) {
+        int acc = incl - mine, med = 4 * lane;
+        const int bins[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (acc <= kmed && acc + bins[q] > kmed) med = 4 * lane + q;
+            acc += bins[q];
+        }
+        ws.median[(size_t)pair * ws.n_regions + ri * rc + rj] = (uint16_t)med;
+    }
+}
+
 // All rounds of one pair in one workgroup (dso.rs:98-147): region thresholds, then up to three rounds of
 //   block maxima at the current base size -> two halvings -> picking at the three levels -> decision,
 // with workgroup barriers between the phases (the planes live in global memory; a barrier orders them within the workgroup).
@@ -148,9 +250,21 @@ template <typename F>
 __device__ __forceinline__ void dso_for_each(int n, F f) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) f(t);
 }
-__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
+// `out` (when out.gsort is set — the sparse keyframe form): the picks of the final round are also kept as a LIST, and the workgroup turns
+// it straight into what mask_sparse_scan_kernel would extract from the stamp plane — the usable picks (final mask && depth != 0) as
+// (Morton code << 16 | depth) words in out.gsort, their number in *out.count — so that the 307 k-pixel plane is never scanned for ~2000
+// picks (0.97 ms per 4096 pairs). A list that overflows publishes cap_n + 1: the pair is then scanned band by band from the stamps.
+struct DsoListOut {
+    const uint16_t* depth;  // [pairs][S0]
+    uint64_t* gsort;        // per pair at pair * gsort_stride (in 64-bit words)
+    size_t gsort_stride;
+    int* count;             // per pair at pair * count_stride
+    int count_stride, cap_n;
+};
+__device__ __forceinline__ uint32_t morton_part(uint32_t v);
+__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoListOut out) {
     __shared__ DsoState st;
-    __shared__ int s_count;
+    __shared__ int s_count, s_list_n, s_out_n;
     const int pair = select_pair(g, blockIdx.x);
     if (pair < 0) return;
     const int rows = g.lv[0].rows, cols = g.lv[0].cols;
@@ -200,12 +314,36 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
         }
         moff[1] = 0;  // mask of level k >= 1 at moff[k] (level 0 is all true); moff[DSO_LEVELS] receives the discarded last mask
         for (int k = 2; k <= DSO_LEVELS + 1; ++k) moff[k] = moff[k - 1] + r[k - 1] * c[k - 1];
-        if (threadIdx.x == 0) s_count = 0;
+        if (threadIdx.x == 0) {
+            s_count = 0;
+            s_list_n = 0;
+        }
         // level-0 block maxima (dso.rs:192-222): first maximum in column-major order; masks of the next levels all true (dso.rs:259)
         dso_for_each(moff[DSO_LEVELS + 1], [&](int t) { mask1[t] = 1; });
+        const bool dword_blocks = bs == 4 && cols % 4 == 0 && reinterpret_cast<uintptr_t>(gm) % 4 == 0;
         dso_for_each(r[0] * c[0], [&](int t) {
             const int bi = t / c[0], bj = t - bi * c[0];
             const int si = bi * bs, sj = bj * bs, ei = min(si + bs, rows), ej = min(sj + bs, cols);
+            if (dword_blocks && ei - si == 4) {  // the first round's 4x4 blocks: four dword loads instead of sixteen byte loads
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const uint32_t*>(gm + (size_t)(si + i) * cols + sj);
+                int mg = (int)(w[0] & 0xff), mi = 0, mj = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int v = (int)((w[i] >> (8 * j)) & 0xff);
+                        if (v > mg) {
+                            mg = v;
+                            mi = i;
+                            mj = j;
+                        }
+                    }
+                max_g[t] = (uint8_t)mg;
+                max_pos[t] = (uint32_t)((si + mi) * cols + sj + mj);
+                return;
+            }
             int mg = gm[(size_t)si * cols + sj], mi = si, mj = sj;
             for (int j = sj; j < ej; ++j)
                 for (int i = si; i < ei; ++i) {
@@ -256,6 +394,10 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
                         mask_next[(i / 2) * nw + j / 2] = 0;
                         picked[pos] = (uint8_t)((round << 2) | (l + 1));
                         ++local;
+                        if (out.gsort) {
+                            const int idx = atomicAdd(&s_list_n, 1);
+                            if (idx < ws.list_cap) ws.pick_list[(size_t)pair * ws.list_cap + idx] = pos;
+                        }
                     }
                 } else {
                     mask_next[(i / 2) * nw + j / 2] = 0;
@@ -291,6 +433,34 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws) {
         __syncthreads();
     }
     if (threadIdx.x == 0) ws.state[pair] = st;
+    if (!out.gsort) return;
+    // the final round's picks -> the usable ones as sort words (any order: mask_sparse_records_kernel sorts them)
+    if (threadIdx.x == 0) s_out_n = 0;
+    __syncthreads();
+    const int n_list = s_list_n;
+    if (n_list > ws.list_cap) {  // (uniform) overflow: leave it to the scan of the stamp plane
+        if (threadIdx.x == 0) out.count[(size_t)pair * out.count_stride] = out.cap_n + 1;
+        return;
+    }
+    const uint32_t* list = ws.pick_list + (size_t)pair * ws.list_cap;
+    const uint16_t* dp = out.depth + (size_t)pair * g.S0;
+    uint64_t* gsort = out.gsort + (size_t)pair * out.gsort_stride;
+    const DsoState fin = st;
+    for (int i = threadIdx.x; i < n_list; i += blockDim.x) {
+        const int t = (int)list[i], y = t / cols, x = t - y * cols;
+        bool m = true;
+        if (fin.random_keep >= 0) {  // random sub-sampling branch (dso.rs:140-143), the same counter hash as dso_final_mask
+            const uint8_t rr8 = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)y << 32) | (uint32_t)x)) & 0xff);
+            m = rr8 <= (uint8_t)fin.random_keep;
+        }
+        const uint32_t dz = dp[t];
+        if (m && dz != 0) {
+            const int o = atomicAdd(&s_out_n, 1);
+            if (o < out.cap_n) gsort[o] = ((uint64_t)(morton_part((uint32_t)y) | (morton_part((uint32_t)x) << 1)) << 16) | dz;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out.count[(size_t)pair * out.count_stride] = s_out_n;  // (> cap_n: band mode, like the scan kernel's overflow)
 }
 __device__ __forceinline__ uint8_t dso_final_mask(const DsoState& st, int stamp, int t, int cols) {
     bool m = (stamp & 3) != 0 && (stamp >> 2) == st.final_round;
@@ -347,10 +517,15 @@ __global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uin
 }
 
 // Selection up to the pick stamps (gradient magnitude + region medians, then all rounds of one pair in one workgroup).
-static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pairs, hipStream_t s) {
+static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pairs, hipStream_t s, DsoListOut out = DsoListOut{}) {
     const bool wide_img = g.lv[0].cols % 4 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 4 == 0;
-    hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
-    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(1024), 0, s, g, ws);
+    if (g.lv[0].cols % 16 == 0 && g.S0 % 16 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 16 == 0) {
+        const int rr = (g.lv[0].rows + DSO_REGION - 1) / DSO_REGION, strips = (g.lv[0].cols + 127) / 128;
+        hipLaunchKernelGGL(dso_gradmag_median_strip_kernel, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+    } else {
+        hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
+    }
+    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(1024), 0, s, g, ws, out);
 }
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
@@ -733,7 +908,7 @@ __device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1,
                     if (bq && (!q.from_stamps || dso_final_mask(q.st, bq, t0 + k, q.cols0))) bits |= 1u << k;
                 }
             }
-            if (q.from_stamps) {
+            if (q.from_stamps && q.mout) {
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 16; ++k) o[k >> 2] |= ((bits >> k) & 1u) << (8 * (k & 3));
@@ -744,7 +919,7 @@ __device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1,
                 const int bq = q.src[t0 + k];
                 const bool m = bq && (!q.from_stamps || dso_final_mask(q.st, bq, t0 + k, q.cols0));
                 if (m) bits |= 1u << k;
-                if (q.from_stamps) q.mout[t0 + k] = m ? 1 : 0;
+                if (q.from_stamps && q.mout) q.mout[t0 + k] = m ? 1 : 0;
             }
         }
         uint32_t usable = 0;
@@ -898,7 +1073,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S0 = g.S0, cols0 = g.lv[0].cols;
     const uint8_t* src = (from_stamps ? ws.picked : mask) + (size_t)pair * S0;
-    uint8_t* mout = mask + (size_t)pair * S0;
+    uint8_t* mout = mask ? mask + (size_t)pair * S0 : nullptr;
     const uint16_t* dp = depth + (size_t)pair * S0;
     uint64_t* gsort = reinterpret_cast<uint64_t*>(pp.v + (size_t)pair * pp.stride);
     // 16-byte loads need 16-byte aligned planes: the mask / stamp planes are the handle's own (hipMalloc), the depth map is the caller's
@@ -928,7 +1103,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
                         if ((w[k >> 2] >> (8 * (k & 3))) & 0xff) bits |= 1u << k;
                 }
             }
-            if (from_stamps && t0 < S0) {
+            if (from_stamps && mask && t0 < S0) {  // (the mask plane is only kept for the plane path: the sparse form passes nullptr)
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 16; ++k) o[k >> 2] |= ((bits >> k) & 1u) << (8 * (k & 3));
@@ -954,7 +1129,7 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
                 const int bq = src[t0 + k];
                 const bool m = bq && (!from_stamps || dso_final_mask(st, bq, t0 + k, cols0));
                 if (m && dp[t0 + k] != 0) us |= 1u << k;
-                if (from_stamps) mout[t0 + k] = m ? 1 : 0;
+                if (from_stamps && mout) mout[t0 + k] = m ? 1 : 0;
             }
             usable[u] = us;
             mine += __popc(us);
@@ -1011,7 +1186,7 @@ __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const
     uint32_t* gset = reinterpret_cast<uint32_t*>(pp.iz + (size_t)pair * pp.stride);
     SparseScan q;
     q.src = (from_stamps ? ws.picked : mask) + (size_t)pair * S0;
-    q.mout = mask + (size_t)pair * S0;
+    q.mout = mask ? mask + (size_t)pair * S0 : nullptr;
     q.dp = depth + (size_t)pair * S0;
     q.gsort = gsort;
     q.st = DsoState{};
@@ -1069,18 +1244,27 @@ __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const
 void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
                          hipStream_t s) {
     const bool fused = g.L >= 2 && g.lv[0].cols % 16 == 0 && g.lv[0].rows % 2 == 0;
-    launch_dso_selection(g, kf, ws, n_pairs, s);
     // Sparse form whenever the pair's pixel planes (its scratch) hold every pixel of one band of tile rows (then any mask works: denser
     // ones go through in several groups of bands); VORS_DSO_PLANES=1 forces the plane path.
     int cap_n = 1;
     while (2 * cap_n <= pp.stride / 3) cap_n *= 2;
     static const bool force_planes = getenv("VORS_DSO_PLANES") && atoi(getenv("VORS_DSO_PLANES")) != 0;
     if (!force_planes && cap_n >= (1 << (g.L - 1)) * g.lv[0].cols && g.lv[0].cols < 65536 && g.lv[0].rows < 65536) {  // a band alone fits
-        launch_zero_ints(g, pp.counts, pp.chunks_total, n_pairs, s);
-        hipLaunchKernelGGL(mask_sparse_scan_kernel, dim3((g.S0 + 256 * 16 * SCAN_U - 1) / (256 * 16 * SCAN_U), n_pairs), dim3(256), 0, s, g, depth, mask, ws, 1, pp, cap_n);
-        hipLaunchKernelGGL(mask_sparse_records_kernel, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, mask, ws, 1, pp, rec, cap_n);
+        // (from the pick stamps: nobody reads the final mask plane in this form, so it is not written)
+        uint8_t* no_mask = nullptr;
+        static const bool use_scan = getenv("VORS_DSO_SCAN") && atoi(getenv("VORS_DSO_SCAN")) != 0;
+        if (use_scan) {  // the usable picks extracted by a pass over the stamp plane (round 2's form; same lists after the sort)
+            launch_dso_selection(g, kf, ws, n_pairs, s);
+            launch_zero_ints(g, pp.counts, pp.chunks_total, n_pairs, s);
+            hipLaunchKernelGGL(mask_sparse_scan_kernel, dim3((g.S0 + 256 * 16 * SCAN_U - 1) / (256 * 16 * SCAN_U), n_pairs), dim3(256), 0, s, g, depth, no_mask, ws, 1, pp, cap_n);
+        } else {         // the selection rounds hand their picks over as a list: the 307 k-pixel plane is not scanned for ~2000 picks
+            launch_dso_selection(g, kf, ws, n_pairs, s,
+                                 DsoListOut{depth, reinterpret_cast<uint64_t*>(pp.v), (size_t)pp.stride / 2, pp.counts, pp.chunks_total, cap_n});
+        }
+        hipLaunchKernelGGL(mask_sparse_records_kernel, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
         return;
     }
+    launch_dso_selection(g, kf, ws, n_pairs, s);
     if (!fused) hipLaunchKernelGGL(dso_finalize_kernel, dim3((g.S0 + 4095) / 4096, n_pairs), dim3(256), 0, s, g, ws, mask);
     keyframe_from_mask(g, kf, depth, mask, pp, rec, fused ? &ws : nullptr, n_pairs, s);
 }

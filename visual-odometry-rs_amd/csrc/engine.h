@@ -95,7 +95,8 @@ struct DsoWs {
     uint8_t* mask1;     // [mask_stride] block masks of levels 1 and 2 (+ the discarded mask after the last level)
     uint8_t* picked;    // [S0] 0 or (round << 2 | level + 1) of the pick
     DsoState* state;    // [1]
-    int n_regions, max_stride, mask_stride;
+    uint32_t* pick_list;  // [list_cap] pixel positions picked in the round in progress (the last round executed = the final one)
+    int n_regions, max_stride, mask_stride, list_cap;
 };
 // Evaluation rounds on the finest levels (dense mode, lm_kernels.hip "split" path): the coarse levels run in the per-pair
 // kernel; then every ROUND is one launch that evaluates the energy of each still-active pair at ITS current level and
