@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
 import numpy as np
 
-ROWS, COLS, L = 480, 640, 6
+ROWS, COLS, L = (int(x) for x in os.environ.get("ABL_SHAPE", "480,640,6").split(","))  # rows, cols, levels
 MODES = {"c2f": 0, "dense": 1, "dso": 2}
 
 
@@ -30,7 +30,7 @@ def worker(args):
     for mode, n in (("c2f", args.c2f), ("dense", args.dense), ("dso", args.dso)):
         if n <= 0:
             continue
-        ref = np.load(f"/tmp/abl_oracle_{mode}_{n}.npz")
+        ref = np.load(f"/tmp/abl_oracle_{mode}_{n}_{ROWS}x{COLS}_L{L}.npz")
         kg, kd, cg, _, gt = V.synth_render_pairs(seed_of(mode), n, ROWS, COLS, intr)
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=MODES[mode], arithmetic=arith)
         b = V.Batch(cfg, n, ROWS, COLS)
@@ -84,7 +84,7 @@ def main():
     from oracle import oracle as O
     intr = O.scaled_intrinsics(ROWS, COLS)
     for mode, n in (("c2f", args.c2f), ("dense", args.dense), ("dso", args.dso)):
-        path = f"/tmp/abl_oracle_{mode}_{n}.npz"
+        path = f"/tmp/abl_oracle_{mode}_{n}_{ROWS}x{COLS}_L{L}.npz"
         if n <= 0 or os.path.exists(path):
             continue
         kg, kd, cg, _, _ = V.synth_render_pairs(seed_of(mode), n, ROWS, COLS, intr)
@@ -114,7 +114,7 @@ def main():
         for mode in ("c2f", "dense", "dso"):
             if mode in d:
                 m = d[mode]
-                print(f"[{spec}] {mode} x{m['n']}: >1e-4: {m['n_beyond_1e-4']} (acc64: {m['acc64_beyond_1e-4']}, shared {m['also_acc64_outliers']}) >1e-5: {m['n_beyond_1e-5']} "
+                print(f"[{spec}] {COLS}x{ROWS} L{L} {mode} x{m['n']}: >1e-4: {m['n_beyond_1e-4']} (acc64: {m['acc64_beyond_1e-4']}, shared {m['also_acc64_outliers']}) >1e-5: {m['n_beyond_1e-5']} "
                       f"median {m['median']:.2e} p99 {m['p99']:.2e} max {m['max']:.2e}; same iters {m['same_iters']:.1%}; fork levels of outliers {m['fork_level_hist_outliers']}; "
                       f"{m['ms_per_step']} ms/step, LM {m['lm_ms']} ms; status_equal {m['status_equal']}", flush=True)
         with open(os.path.join(ROOT, "gpurun_out", "ablate.jsonl"), "a") as f:
