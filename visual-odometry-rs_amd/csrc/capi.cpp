@@ -841,9 +841,9 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
     return VORS_OK;
 }
 
-// The heart of vors_trackers_track for ONE sequence whose depth map arrives on another stream (defined with the lock-step engine).
-vors_status vors_trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
-                                            hipStream_t s);
+// vors_trackers_track with the depth map arriving on another stream (internal; defined with the lock-step engine below).
+static vors_status trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
+                                              hipStream_t s);
 
 vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
                                int* track_status) {
@@ -853,7 +853,7 @@ vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_
     if (st != VORS_OK) return st;
     // Tracker::track (inverse_compositional.rs:170-240) incl. the keyframe switch, all on the device; the promotion (the only reader of
     // the depth map) waits for its upload
-    st = vors_trackers_track_depth_event(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main);
+    st = trackers_track_depth_event(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main);
     if (st != VORS_OK) return st;
     HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
     const float* d_pose = nullptr;
@@ -1008,13 +1008,13 @@ vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const ui
 }
 
 vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream) {
-    return vors_trackers_track_depth_event(t, d_gray, d_depth, nullptr, static_cast<hipStream_t>(hip_stream));
+    return trackers_track_depth_event(t, d_gray, d_depth, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
 // depth_ready (nullable): an event after which d_depth holds this frame's depth map (uploaded on another stream); it is waited for just
 // before the promotion, the only reader of the depth map.
-vors_status vors_trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
-                                            hipStream_t s) {
+static vors_status trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
+                                              hipStream_t s) {
     if (!t || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!t->initialised) return fail(VORS_ERR_INVALID_ARGUMENT, "vors_trackers_track called before vors_trackers_init");
     vors_batch* b = t->batch;
