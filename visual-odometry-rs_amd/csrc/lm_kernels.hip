@@ -59,7 +59,7 @@ constexpr bool kFused = VORS_FUSED != 0;
 #define LM_MAX_WAVES 16
 
 struct LmShared {
-    float part[LM_MAX_WAVES * 4 * 32];  // partial sums per 16-lane row of each wavefront
+    alignas(16) float part[LM_MAX_WAVES * 4 * 32];  // partial sums per 16-lane row of each wavefront (block_reduce: slot (v & 3) * 8 + (v >> 2) = sum v)
     float sums[2][32];              // ping-pong totals: [cur] = kept state's sums, [1-cur] = candidate's
     float cand[8];                  // candidate model (7) + step-ok flag, broadcast from the solving lane
     float misc[LM_MAX_WAVES * 2];
@@ -1079,25 +1079,47 @@ __device__ __forceinline__ float row_sum16(float v) {
     v = dpp_add_row<0x140>(v);  // row_mirror
     return v;
 }
-// Workgroup reduction of the 29 partial sums into s.sums[dst][0..28]: four DPP steps inside each 16-lane row (116 instructions per
-// wavefront), the row sums go to LDS straight from one lane per row, 29 threads add the BLOCK / 16 rows in index order. (The first
-// version went on to lane 63 with row_bcast steps and fetched every total with v_readlane + a select: 437 instructions per wavefront
-// and evaluation — 18 % of the coarse-level kernel.) Deterministic for a given BLOCK. Ends with a barrier.
+// Workgroup reduction of the 29 partial sums into s.sums[dst][0..28]. Round 3 measured this at ~28 % of the per-pair kernel in the sparse
+// modes (probes by doubling; tools/ubench/dpp_ops: a DPP add issues every 4.4 cycles, not 2.8, and each of the 29 LDS stores by 4 of 64
+// lanes costs 10-16), so it is a TRANSPOSING reduction now: the two in-quad steps halve the number of values a lane carries — an even
+// lane keeps sum 2j and gives 2j+1 to its neighbour, and so on: a lane of quad position q ends with the 8 sums v = 4 k + q (two selects
+// + one DPP add per output; DPP bank masks select quads, not lanes, so the selects cannot be folded away) — then two row_shl steps add
+// the four quads of a row into its first quad, whose 4 lanes hand the row's 32 sums over with two 16-byte LDS stores; 29 threads add
+// the BLOCK / 16 rows in index order as before. 88 VALU instructions + 2 stores per wavefront instead of 116 + 29, and the SAME
+// floating-point result bit for bit: every sum is still ((l0 + l1) + (l2 + l3)) within a quad and (Q0 + Q1) + (Q2 + Q3) within a row
+// (tools/ubench/reduce_check.hip compares the two forms). Deterministic for a given BLOCK. Ends with a barrier.
 template <int BLOCK>
 __device__ __forceinline__ void block_reduce(const float acc[NACC], LmShared& s, int dst) {
-    float r[NACC];
+    float a[32];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) r[i] = row_sum16(acc[i]);
-    if ((threadIdx.x & 15) == 0) {
-        float* p = s.part + (threadIdx.x >> 4) * 32;
+    for (int i = 0; i < 32; ++i) a[i] = i < NACC ? acc[i] : 0.f;
+    float b[16], c[8];
+    const bool odd = (threadIdx.x & 1) != 0, hi = (threadIdx.x & 2) != 0;
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) p[i] = r[i];
+    for (int j = 0; j < 16; ++j) {  // lane ^ 1: an even lane keeps sum 2j, an odd lane sum 2j+1; each gives the other one away
+        const float keep = odd ? a[2 * j + 1] : a[2 * j], give = odd ? a[2 * j] : a[2 * j + 1];
+        b[j] = keep + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // lane ^ 2: lanes 0, 1 of a quad keep b[2k], lanes 2, 3 keep b[2k+1]
+        const float keep = hi ? b[2 * k + 1] : b[2 * k], give = hi ? b[2 * k] : b[2 * k + 1];
+        c[k] = keep + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c[k]), 0x104, 0xf, 0xf, true));  // row_shl:4: Q0 + Q1
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c[k]), 0x108, 0xf, 0xf, true));  // row_shl:8: + (Q2 + Q3)
+    if ((threadIdx.x & 15) < 4) {
+        float4* p = reinterpret_cast<float4*>(s.part + (threadIdx.x >> 4) * 32 + (threadIdx.x & 3) * 8);
+        p[0] = make_float4(c[0], c[1], c[2], c[3]);
+        p[1] = make_float4(c[4], c[5], c[6], c[7]);
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
+        const int slot = (threadIdx.x & 3) * 8 + (threadIdx.x >> 2);
         float t = 0.f;
 #pragma unroll 8
-        for (int w = 0; w < BLOCK / 16; ++w) t += s.part[w * 32 + threadIdx.x];
+        for (int w = 0; w < BLOCK / 16; ++w) t += s.part[w * 32 + slot];
         s.sums[dst][threadIdx.x] = t;
     }
     __syncthreads();
