@@ -26,3 +26,23 @@ for mode in (0, 1, 2):
     del kg, kd, cg, poses, status, stats
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     print(f"mode {mode}: 60 handles x 5 steps, bit-identical poses every time; free memory delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")
+# single-sequence trackers (streams, events, pinned staging) and lock-step handles: create / track / destroy
+g = np.random.default_rng(0).integers(0, 255, (rows, cols), dtype=np.uint8)
+d = np.full((rows, cols), 9000, np.uint16)
+for mode in (0, 1, 2):
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=1)
+    for it in range(40):
+        t = cfg.init(0.0, d, 0.0, g)
+        for k in range(3):
+            t.track(float(k + 1), d, float(k + 1), g)
+        del t
+    for it in range(20):
+        tr = V.Trackers(cfg, 16, rows, cols)
+        gg = torch.from_numpy(np.repeat(g[None], 16, 0)).cuda(); dd = torch.from_numpy(np.repeat(d[None], 16, 0).view(np.int16)).cuda()
+        tr.init(gg, dd)
+        for k in range(3):
+            tr.track(gg, dd)
+        tr.current_frames()
+        del tr, gg, dd
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    print(f"mode {mode}: 40 trackers + 20 lock-step handles created / tracked / destroyed; free memory delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")
