@@ -287,10 +287,12 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
     // workgroups, several per CU, so that pairs with different iteration counts balance (measured).
     // (sparse modes, many pairs: 128 threads — the candidate lists are short, small workgroups waste fewer lanes at the coarse levels and
     // more of them are resident: coarse-to-fine LM stage 1.61 -> 1.28 ms per 4096 pairs)
-    b->lm_block = max_pairs >= 512 ? (g.mode == VORS_CANDIDATES_DENSE ? 256 : 128) : (g.mode == VORS_CANDIDATES_DENSE ? 1024 : 512);
-    // (DSO lists are ~2000 candidates per level: 256 threads halve the dependent load -> warp -> tap iterations of an evaluation:
-    // LM stage 2.33 -> 2.11 ms per 4096 pairs)
-    if (g.mode == VORS_CANDIDATES_DSO && max_pairs >= 512) b->lm_block = 256;
+    // Round 3: the thresholds below come from tools/speed_sweep.py over 320x240 / 640x480 / 1280x960 x 64 ... 4096 pairs (the round-2 ones
+    // were fitted at 640x480 with 256 and 4096 pairs and cost 15-25 % at 512 coarse-to-fine pairs, 2.6x at 64 dense 1280x960 pairs):
+    // the best size depends on the BATCH, hardly on the shape — the chip wants ~100 k resident threads whatever a pair is made of.
+    if (g.mode == VORS_CANDIDATES_DENSE) b->lm_block = max_pairs >= 512 ? 256 : 1024;
+    else if (g.mode == VORS_CANDIDATES_DSO) b->lm_block = max_pairs <= 768 ? 512 : 256;  // (lists of ~2000 candidates per level)
+    else b->lm_block = max_pairs <= 768 ? 512 : (max_pairs < 1536 ? 256 : 128);
     if (const char* e = getenv("VORS_LM_BLOCK")) {  // tuning knob (256 / 512 / 1024)
         const int v = atoi(e);
         if (v != 64 && v != 128 && v != 256 && v != 512 && v != 1024) {
@@ -356,7 +358,7 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         // small ones (down to the single tracker) still spread one evaluation over the chip.
         // `chunks` = partial-sum slots per pair = the late-round cut (at least 512 pixels each); the full rounds use a quarter of it
         int chunks = max_pairs >= 1024 ? 64 : (max_pairs >= 128 ? 128 : 256);
-        chunks = std::max(4, std::min(chunks, g.S0 / 512));
+        chunks = std::max(4, std::min(chunks, g.S0 / 2400));  // (at least ~2400 pixels per chunk: 320x240 wants 32, not 64-150)
         if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(4, atoi(ev));
         b->split.chunks = chunks;
         // levels worth a chip-wide launch per evaluation: at least 64 Ki pixels (640x480: levels 0 and 1; 1280x960: 0, 1, 2)
@@ -364,7 +366,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         for (int l = 0; l < g.L; ++l)
             if ((long long)g.lv[l].rows * g.lv[l].cols >= 65536) n_split = l + 1;
         b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : std::max(1, n_split);
-        b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? 26 : (max_pairs >= 100 ? 16 : 10));
+        // rounds before the per-pair finish: a level solved by rounds needs >= 2 of them per evaluation pattern, so the count follows the
+        // number of such levels (1280x960 has three: 10 rounds left 64 pairs 2.6x slower than 16)
+        const int ns = b->split.n_split;
+        b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? (ns <= 1 ? 12 : 26) : 4 * ns + 8);
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
