@@ -176,10 +176,11 @@ vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t*
 typedef struct vors_batch vors_batch;
 /* Scheduling knobs (environment, read at create(); results stay within the stated tolerance whatever their value — they only
  * change how the same arithmetic is spread over the chip; tests/test_gpu_parity.py covers the variants):
- *   VORS_LM_BLOCK=256|512|1024   threads per frame pair in the per-pair LM kernel (default by batch size and mode)
+ *   VORS_LM_BLOCK=64..1024       threads per frame pair in the per-pair LM kernel (default by batch size and mode)
  *   VORS_LM_SPLIT=0              dense mode: one per-pair kernel for all levels instead of evaluation rounds
  *   VORS_LM_SPLIT_LEVELS=n       dense mode: the n finest levels are solved by evaluation rounds (default: levels of >= 64 Ki pixels)
- *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before per-pair workgroups finish the stragglers (default 26 / 16 / 10 by batch size)
+ *   VORS_LM_SPLIT_ROUNDS=n       rounds launched before per-pair workgroups finish the stragglers (default by batch size and by the number
+ *                                of levels solved by rounds; the defaults of all these knobs come from tools/speed_sweep.py)
  *   VORS_LM_CHUNKS=n             partial-sum chunks per pair of a level-0 evaluation (default by batch size)
  *   VORS_KF_R=1|2|4|8            tree roots per wavefront in the coarse-to-fine keyframe kernel (default 4)
  *   VORS_NO_FASTDIV=1            plain IEEE division by the focal lengths (the verified 3-instruction form is bit-identical)
