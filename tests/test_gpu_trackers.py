@@ -129,3 +129,40 @@ def test_config3_shape_640x480_dso_sequence_of_60_frames_vs_oracle(arith):
         switches += int(ot.last()["changed_keyframe"])
     assert switches >= 2
     print(f"60 frames, {switches} keyframe switches, max accumulated pose difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["coarse_to_fine", "dense"])
+def test_sequences_failure_semantics_vs_oracle(mode):
+    """The reference's failure paths inside a SEQUENCE, with the state machine on the device: a keyframe switch onto a frame without any
+    valid depth leaves a keyframe with no candidates — from then on step() fails (Cholesky of a zero Hessian), the pose is KEPT
+    (inverse_compositional.rs:195-199,206-208), the optical flow is 0/0 = NaN and never switches again (:213-224). Sequences 0 and 2 get
+    such a frame at different times, sequence 1 never: statuses, poses and keyframe indices must follow the oracle frame by frame."""
+    rows, cols, L, n_seq, n_frames = 120, 160, 4, 3, 9
+    intr = O.scaled_intrinsics(rows, cols)
+    frames = make_sequences(n_seq, n_frames, rows, cols, intr, blocky=False)
+    host = [(g.cpu().numpy().copy(), d.cpu().numpy().view(np.uint16).copy()) for g, d in frames]
+    # zero the depth of frame 3 in sequence 0 and of frames 5.. in sequence 2 (whichever of them becomes a keyframe kills the sequence)
+    host[3][1][0][:] = 0
+    for k in range(5, n_frames):
+        host[k][1][2][:] = 0
+    import torch
+    dev = [(torch.from_numpy(g).cuda(), torch.from_numpy(d.view(np.int16)).cuda()) for g, d in host]
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=V.ARITH_FUSED)
+    many = V.Trackers(cfg, n_seq, rows, cols)
+    many.init(*dev[0])
+    ots = [O.Tracker(O.make_config(L, intr, candidates_mode=mode), 0.0, host[0][1][s], 0.0, host[0][0][s]) for s in range(n_seq)]
+    failed = 0
+    for k in range(1, n_frames):
+        many.track(*dev[k])
+        poses, status, kf_index = many.current_frames()
+        for s in range(n_seq):
+            ost = ots[s].track(float(k), host[k][1][s], float(k), host[k][0][s])
+            assert ost == status[s], f"frame {k} sequence {s}: status {status[s]} vs oracle {ost}"
+            po = ots[s].current_frame()[1]
+            if ost != 0:
+                failed += 1
+                assert (po == poses[s]).all() or np.abs(po - poses[s]).max() < POSE_TOL, f"frame {k} sequence {s}: kept pose"
+            else:
+                assert np.abs(po - poses[s]).max() < POSE_TOL, f"frame {k} sequence {s}"
+            assert float(kf_index[s]) == ots[s].keyframe_pose()[0], f"frame {k} sequence {s}: keyframe index"
+    assert failed >= 2, "the scenario was meant to kill at least one sequence"
