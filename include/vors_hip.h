@@ -133,7 +133,8 @@ void vors_tracker_destroy(vors_tracker* t);
  *     exactly the sequences whose flow reached the threshold — the promotion of the current frame to keyframe (:227-239:
  *     precompute_multires_data on the current pyramid and THIS call's depth map, keyframe_pose <- current_frame_pose). No host round
  *     trip, no synchronisation: a call only enqueues work on hip_stream. Results per sequence are bit-identical to a vors_tracker fed
- *     the same frames (tests/test_gpu_trackers.py).
+ *     the same frames for handles of fewer than 512 sequences (tests/test_gpu_trackers.py); larger handles are scheduled differently
+ *     (threads per sequence, evaluation rounds), which changes the ORDER of the f32 sums and with it the last bits, nothing else.
  *     Frames: DEVICE buffers, row-major, sequence s at offset s * rows * cols; they are read by the work this call enqueues and by
  *     nothing later (dense mode copies a promoted frame into the handle), so the caller may reuse them once the stream has passed
  *     the call. Timestamps stay with the caller: vors_trackers_state / _current_frames report, per sequence, the index of the frame

@@ -370,6 +370,8 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         // number of such levels (1280x960 has three: 10 rounds left 64 pairs 2.6x slower than 16)
         const int ns = b->split.n_split;
         b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? (ns <= 1 ? 12 : 26) : 4 * ns + 8);
+        // (a lone dense pair would be 8 % faster with 2 * ns rounds, but a vors_tracker must stay bit-identical to a sequence of a
+        // lock-step handle of up to 511 sequences: the same count for every handle below 512 pairs)
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
@@ -779,23 +781,36 @@ struct TrackerOut {  // layout of vors_tracker::h_out
 
 // Frame -> device (row-major). The caller's buffers are pageable: they are copied into pinned staging first, so that the transfers are
 // truly asynchronous (the depth map travels on its own stream under the LM stage).
-static vors_status tracker_upload(vors_tracker* t, const uint8_t* gray, const uint16_t* depth) {
+// Two halves, so that vors_tracker_track can stage the depth map (the larger copy, on the CPU) WHILE the device already runs the pyramid
+// and the LM stage of the frame: only the promotion at the end of the frame reads it.
+static vors_status tracker_upload_gray(vors_tracker* t, const uint8_t* gray) {
     const size_t S = (size_t)t->rows * t->cols;
     std::memcpy(t->h_gray.p, gray, S);
-    std::memcpy(t->h_depth.p, depth, S * 2);
-    // the previous frame's promotion may still read t->depth: the copy stream first waits for the end of the previous frame
-    HIP_TRY(hipStreamWaitEvent(t->s_copy, t->ev_frame_done, 0));
     if (t->layout == VORS_ROW_MAJOR) {
         HIP_TRY(hipMemcpyAsync(t->gray.p, t->h_gray.p, S, hipMemcpyHostToDevice, t->s_main));
-        HIP_TRY(hipMemcpyAsync(t->depth.p, t->h_depth.p, S * 2, hipMemcpyHostToDevice, t->s_copy));
     } else {
         HIP_TRY(hipMemcpyAsync(t->tmp8.p, t->h_gray.p, S, hipMemcpyHostToDevice, t->s_main));
         launch_transpose_u8(t->tmp8.as<uint8_t>(), t->gray.as<uint8_t>(), t->rows, t->cols, 1, t->s_main);
+    }
+    return VORS_OK;
+}
+static vors_status tracker_upload_depth(vors_tracker* t, const uint16_t* depth) {
+    const size_t S = (size_t)t->rows * t->cols;
+    std::memcpy(t->h_depth.p, depth, S * 2);  // (the previous frame has been synchronised: nobody reads the staging buffer any more)
+    // the previous frame's promotion may still read t->depth: the copy stream first waits for the end of the previous frame
+    HIP_TRY(hipStreamWaitEvent(t->s_copy, t->ev_frame_done, 0));
+    if (t->layout == VORS_ROW_MAJOR) {
+        HIP_TRY(hipMemcpyAsync(t->depth.p, t->h_depth.p, S * 2, hipMemcpyHostToDevice, t->s_copy));
+    } else {
         HIP_TRY(hipMemcpyAsync(t->tmp16.p, t->h_depth.p, S * 2, hipMemcpyHostToDevice, t->s_copy));
         launch_transpose_u16(t->tmp16.as<uint16_t>(), t->depth.as<uint16_t>(), t->rows, t->cols, 1, t->s_copy);
     }
     HIP_TRY(hipEventRecord(t->ev_depth, t->s_copy));
     return VORS_OK;
+}
+static vors_status tracker_upload(vors_tracker* t, const uint8_t* gray, const uint16_t* depth) {
+    vors_status st = tracker_upload_gray(t, gray);
+    return st != VORS_OK ? st : tracker_upload_depth(t, depth);
 }
 
 extern "C" {
@@ -849,20 +864,23 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
     return VORS_OK;
 }
 
-// vors_trackers_track with the depth map arriving on another stream (internal; defined with the lock-step engine below).
-static vors_status trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
-                                              hipStream_t s);
+// The two halves of vors_trackers_track (internal; defined with the lock-step engine below): Tracker::track up to the keyframe test,
+// and the promotion of the sequences that switch — the only reader of the depth map, which may arrive on another stream (depth_ready).
+static vors_status trackers_track_lm(vors_trackers* t, const uint8_t* d_gray, hipStream_t s);
+static vors_status trackers_promote(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready, hipStream_t s);
 
 vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_t* depth, double img_time, const uint8_t* gray,
                                int* track_status) {
     if (!t || !depth || !gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     DeviceGuard guard(t->device);
-    vors_status st = tracker_upload(t, gray, depth);
+    // Tracker::track (inverse_compositional.rs:170-240) incl. the keyframe switch, all on the device. Order on the host: grey image up,
+    // pyramid + LM + keyframe test enqueued, THEN the depth map staged and sent on the copy stream (under the LM stage), then the
+    // promotion, which waits for it.
+    vors_status st = tracker_upload_gray(t, gray);
     if (st != VORS_OK) return st;
-    // Tracker::track (inverse_compositional.rs:170-240) incl. the keyframe switch, all on the device; the promotion (the only reader of
-    // the depth map) waits for its upload
-    st = trackers_track_depth_event(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main);
-    if (st != VORS_OK) return st;
+    if ((st = trackers_track_lm(t->seq, t->gray.as<uint8_t>(), t->s_main)) != VORS_OK) return st;
+    if ((st = tracker_upload_depth(t, depth)) != VORS_OK) return st;
+    if ((st = trackers_promote(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main)) != VORS_OK) return st;
     HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
     const float* d_pose = nullptr;
     const int32_t *d_status = nullptr, *d_kf = nullptr;
@@ -1016,14 +1034,14 @@ vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const ui
 }
 
 vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream) {
-    return trackers_track_depth_event(t, d_gray, d_depth, nullptr, static_cast<hipStream_t>(hip_stream));
+    if (!d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    vors_status st = trackers_track_lm(t, d_gray, s);
+    return st != VORS_OK ? st : trackers_promote(t, d_gray, d_depth, nullptr, s);
 }
 
-// depth_ready (nullable): an event after which d_depth holds this frame's depth map (uploaded on another stream); it is waited for just
-// before the promotion, the only reader of the depth map.
-static vors_status trackers_track_depth_event(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready,
-                                              hipStream_t s) {
-    if (!t || !d_gray || !d_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
+static vors_status trackers_track_lm(vors_trackers* t, const uint8_t* d_gray, hipStream_t s) {
+    if (!t || !d_gray) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!t->initialised) return fail(VORS_ERR_INVALID_ARGUMENT, "vors_trackers_track called before vors_trackers_init");
     vors_batch* b = t->batch;
     DeviceGuard guard(b->device);
@@ -1038,6 +1056,15 @@ static vors_status trackers_track_depth_event(vors_trackers* t, const uint8_t* d
     // :203-208 and :224-239 on the device: poses forward, promotion list
     launch_trackers_advance(n, t->frame_index, t->out_poses.as<float>(), t->stats.as<vors_pair_stats>(), t->cur_poses.as<float>(),
                             t->kf_poses.as<float>(), t->kf_frame.as<int32_t>(), t->promo_list.as<int>(), t->promo_count.as<int>(), s);
+    HIP_TRY(hipGetLastError());
+    return VORS_OK;
+}
+
+// depth_ready (nullable): an event after which d_depth holds this frame's depth map (uploaded on another stream).
+static vors_status trackers_promote(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, hipEvent_t depth_ready, hipStream_t s) {
+    vors_batch* b = t->batch;
+    DeviceGuard guard(b->device);
+    const int n = t->n_seq;
     // precompute_multires_data (:230-235) for the promoted sequences only: the pyramid of the current frame is reused, the depth map is
     // the one that came with it
     Geom gm = b->g;
