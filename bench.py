@@ -367,13 +367,13 @@ def sequences_bench(V, args, device, n_seq=64, n_frames=40):
     speed = 0.5 + 1.0 * rng.random(n_seq)
     sign = rng.choice([-1.0, 1.0], size=(n_seq, 6))
     out = {}
-    for mode in ("c2f", "dso"):
+    for mode in ("c2f", "dso", "dense"):
         blocky = (1 << 63) if mode == "dso" else 0
         frames = []
         for k in range(n_frames):
             frames.append(V.synth_render_frames([blocky | (4242 + s) for s in range(n_seq)], [k] * n_seq,
                                                 [base * sign[s] * speed[s] * k for s in range(n_seq)], rows, cols, intr, device=device))
-        mode_id = {"c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO}[mode]
+        mode_id = {"c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO, "dense": V.CANDIDATES_DENSE}[mode]
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode_id,
                        arithmetic=V.ARITH_FUSED if args.arith == "fused" else V.ARITH_EXACT)
         tr = V.Trackers(cfg, n_seq, rows, cols)
