@@ -98,6 +98,8 @@ def test_trackers_argument_checks():
     with pytest.raises(V.VorsError):
         t.track(g, d)  # before init
     with pytest.raises(V.VorsError):
+        t.current_frames()
+    with pytest.raises(V.VorsError):
         t.init(g[:1], d[:1])
     t.init(g, d)
     t.track(g, d)      # no usable candidate anywhere: the pose stays the identity, like the reference

@@ -1101,6 +1101,7 @@ vors_status vors_trackers_state(const vors_trackers* t, const float** d_current_
 
 vors_status vors_trackers_current_frames(vors_trackers* t, float* poses7, int32_t* status, int32_t* keyframe_index, void* hip_stream) {
     if (!t) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!t->initialised) return fail(VORS_ERR_INVALID_ARGUMENT, "vors_trackers_current_frames called before vors_trackers_init");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     DeviceGuard guard(t->batch->device);
     const size_t n = (size_t)t->n_seq;
