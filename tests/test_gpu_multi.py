@@ -71,3 +71,30 @@ def test_create_on_rejects_bad_device_and_foreign_stream():
             p = torch.zeros((2, 7), device="cuda:0"); s = torch.zeros(2, dtype=torch.int32, device="cuda:0")
             with pytest.raises(V.VorsError, match="stream belongs to device"):
                 b.track_pairs(t[0], t[1], t[2], p, s)
+
+
+def test_kernel_timing_on_a_handle_of_another_device_and_multi_argument_checks():
+    """the timing events of a handle belong to the handle's device whatever the caller's current device is (cross-device part
+    needs >= 2 GPUs; on one GPU the same calls run on device 0); MultiGpu.track_pairs_host rejects arrays that do not hold n pairs each."""
+    import torch
+    rows, cols, L, n = 64, 96, 3, 4
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, _, _ = O.synth_batch(n, rows, cols, seed0=3, intr=intr)
+    dev = V.device_count() - 1          # the LAST device; the caller stays on device 0
+    torch.cuda.set_device(0)
+    b = V.Batch(_cfg(L, intr, 0), n, rows, cols, device=dev)
+    b.enable_kernel_timing(4)
+    t = [torch.from_numpy(a).cuda(dev) for a in (kg, kd.view(np.int16), cg)]
+    p = torch.zeros((n, 7), device=f"cuda:{dev}"); s = torch.zeros(n, dtype=torch.int32, device=f"cuda:{dev}")
+    with torch.cuda.device(dev):
+        b.track_pairs(t[0], t[1], t[2], p, s)
+        torch.cuda.synchronize(dev)
+    assert torch.cuda.current_device() == 0
+    ms = b.kernel_times("lm")
+    assert len(ms) == 1 and ms[0] > 0 and b.last_kernel_ms()["lm_ms"] > 0
+    m = V.MultiGpu(_cfg(L, intr, 0), n, rows, cols)
+    assert m.rccl_version() == 0 or V.device_count() >= 2
+    with pytest.raises(V.VorsError):
+        m.track_pairs_host(kg, kd[: n - 1], cg)
+    with pytest.raises(V.VorsError):
+        m.track_pairs_host(kg, kd, cg[:, : rows - 1])
