@@ -62,7 +62,10 @@ __device__ __forceinline__ void grad_tmpl_at(const Geom& g, const uint8_t* level
     } else {
         const int fc = g.lv[l - 1].cols;
         const uint8_t* p = level_ptr(g, level0, upper, pair, l - 1) + (size_t)(2 * y) * fc + 2 * x;
-        const int a = p[0], c = p[1], b = p[fc], d = p[fc + 1];
+        uint16_t r0, r1;  // the 2x2 block as two (possibly unaligned) 16-bit loads instead of four byte loads
+        __builtin_memcpy(&r0, p, 2);
+        __builtin_memcpy(&r1, p + fc, 2);
+        const int a = r0 & 0xff, c = r0 >> 8, b = r1 & 0xff, d = r1 >> 8;
         *gx = (c + d - a - b) / 2;
         *gy = (b - a + d - c) / 2;
         *tm = (a + b + c + d) >> 2;
