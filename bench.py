@@ -542,6 +542,10 @@ def main():
         # the stage at the device's PEAK clock (hipDeviceAttributeClockRate; a throttled clock makes the true fraction larger)
         "shader_clock_hz_peak": clock_hz,
         "valu_issue_frac": (round(cnt["sq_insts_valu"] * 2.0 / (N_SIMD * lm_avg_s * clock_hz), 4) if "sq_insts_valu" in cnt else None),
+        # the same with the issue interval MEASURED on this chip for the fastest class (v_fma / v_mul / v_add: one wave64 instruction per
+        # 2.8 cycles per SIMD, tools/ubench/valu_ops, pk_ops; v_pk_fma_f32 5.06 per pair; conversions / compares / selects / DPP 4.4)
+        "valu_issue_frac_at_measured_2p8_cycles": (round(cnt["sq_insts_valu"] * 2.8 / (N_SIMD * lm_avg_s * clock_hz), 4)
+                                                   if "sq_insts_valu" in cnt else None),
         # share of the wavefronts' resident time in which a VALU instruction of theirs is executing (both counters are per-wave quad-cycle
         # sums: a ratio of like units, <= 1 by construction — the r02 `valu_busy_frac` divided a per-wave sum by SIMD-cycles and could exceed 1)
         "valu_active_over_wave_cycles": (round(cnt["sq_active_inst_valu"] / cnt["sq_wave_cycles"], 4)
