@@ -511,9 +511,11 @@ def main():
 
     traffic = cnt.get("traffic_bytes")
     roofline = {
-        # What binds the dominant stage is VALU issue, not the memory system (memory_side_frac below); `frac` stays what SURVEY §8(d)
-        # defines — algorithmic bytes over the stage's measured time against the 8 TB/s HBM roofline.
-        "bound": "valu",
+        # `bound` names the roofline `achieved` / `peak` / `frac` are taken against (the bench contract knows "hbm" and "mfma"): SURVEY
+        # §8(d)'s algorithmic bytes over the stage's measured time vs the 8 TB/s HBM peak. What LIMITS the stage is `limited_by`: VALU
+        # issue — its memory side is at `memory_side_frac` of the peak.
+        "bound": "hbm",
+        "limited_by": "valu",
         "model": "hbm: SURVEY §8(d) algorithmic bytes / measured stage time vs 8 TB/s",
         # dense mode: the LM stage is a short sequence of launches (coarse levels per pair, then one launch per energy evaluation round on
         # the finest levels + a per-pair step launch, then the per-pair epilogue); it is timed as a whole with HIP events on its stream,
