@@ -162,3 +162,34 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["pairs_per_gpu"] == 64 and d["failed_pairs"] == 0
     assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # whole-job aggregate over both ranks
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_json_contract():
+    """The ONE JSON line of `python bench.py` (N = 1) carries every key the driver's contract names, with the contract's vocabulary
+    (roofline.bound in {hbm, mfma}; cpu_baseline.kind in {reference, port}), and its numbers are self-consistent."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--pairs", "64", "--steps", "3", "--warmup", "1", "--cpu-pairs", "4",
+                        "--parity-pairs", "16", "--no-sequences", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    assert d["parity"]["status_equal"] and d["parity"]["n_beyond_tol"] <= d["parity"]["n_beyond_tol_oracle_f32_vs_f64_accumulation"] + 1
