@@ -142,6 +142,8 @@ void vors_tracker_destroy(vors_tracker* t);
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct vors_trackers vors_trackers;
 vors_status vors_trackers_create(const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out);
+/* Same on an explicit HIP device (several GPUs = one handle per device, each with its own sequences: "replicas only", like batches). */
+vors_status vors_trackers_create_on(int device, const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out);
 int vors_trackers_count(const vors_trackers* t);
 vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream);
 vors_status vors_trackers_track(vors_trackers* t, const uint8_t* d_gray, const uint16_t* d_depth, void* hip_stream);

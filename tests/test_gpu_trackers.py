@@ -105,6 +105,13 @@ def test_trackers_argument_checks():
     t.track(g, d)      # no usable candidate anywhere: the pose stays the identity, like the reference
     poses, status, kf = t.current_frames()
     assert (poses == np.array([0, 0, 0, 0, 0, 0, 1], np.float32)).all()
+    # the explicit-device constructor: device 0 behaves like the default, a device that does not exist is refused
+    t0 = V.Trackers(cfg, 2, rows, cols, device=0)
+    t0.init(g, d)
+    t0.track(g, d)
+    assert (t0.current_frames()[0] == poses).all()
+    with pytest.raises(V.VorsError):
+        V.Trackers(cfg, 2, rows, cols, device=torch.cuda.device_count())
 
 
 @pytest.mark.parametrize("arith", [V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])

@@ -964,11 +964,21 @@ struct vors_trackers {
 extern "C" {
 
 vors_status vors_trackers_create(const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    return vors_trackers_create_on(dev, cfg, n_sequences, rows, cols, out);
+}
+
+vors_status vors_trackers_create_on(int device, const vors_config* cfg, int n_sequences, int rows, int cols, vors_trackers** out) {
     if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     vors_batch* b = nullptr;
-    vors_status st = vors_batch_create(cfg, n_sequences, rows, cols, &b);
+    vors_status st = vors_batch_create_on(device, cfg, n_sequences, rows, cols, &b);
     if (st != VORS_OK) return st;
+    DeviceGuard on_device(device);  // the state buffers live on the handle's device
     vors_trackers* t = new vors_trackers();
     t->batch = b;
     t->n_seq = n_sequences;

@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "vors_synth_render_pairs",
     "vors_multi_create", "vors_multi_device_count", "vors_multi_shard", "vors_multi_track_pairs", "vors_multi_track_pairs_host",
     "vors_multi_destroy", "vors_multi_rccl_version",
-    "vors_trackers_create", "vors_trackers_count", "vors_trackers_init", "vors_trackers_track", "vors_trackers_state",
+    "vors_trackers_create", "vors_trackers_create_on", "vors_trackers_count", "vors_trackers_init", "vors_trackers_track", "vors_trackers_state",
     "vors_trackers_current_frames", "vors_trackers_last_stats", "vors_trackers_enable_kernel_timing", "vors_trackers_kernel_times", "vors_trackers_destroy",
     "vors_synth_render_frames",
 ]
@@ -149,6 +149,7 @@ def lib():
         _lib.vors_multi_destroy.restype = None
         _lib.vors_multi_rccl_version.argtypes = [vp]
         _lib.vors_trackers_create.argtypes = [C.POINTER(vors_config), i, i, i, C.POINTER(vp)]
+        _lib.vors_trackers_create_on.argtypes = [i, C.POINTER(vors_config), i, i, i, C.POINTER(vp)]
         _lib.vors_trackers_count.argtypes = [vp]
         _lib.vors_trackers_init.argtypes = [vp, vp, vp, vp]
         _lib.vors_trackers_track.argtypes = [vp, vp, vp, vp]
@@ -523,11 +524,14 @@ class Trackers:
     """N sequences in lock-step, device resident (vors_trackers_*): Config::init / Tracker::track / current_frame for every
     sequence with the whole tracker state machine (poses, keyframe test, per-sequence keyframe promotion) on the device."""
 
-    def __init__(self, config, n_sequences, rows, cols):
+    def __init__(self, config, n_sequences, rows, cols, device=None):
         self.config, self.n, self.rows, self.cols = config, n_sequences, rows, cols
         self._h = C.c_void_p()
         cfg = config.to_c()
-        _check(lib().vors_trackers_create(C.byref(cfg), n_sequences, rows, cols, C.byref(self._h)))
+        if device is None:
+            _check(lib().vors_trackers_create(C.byref(cfg), n_sequences, rows, cols, C.byref(self._h)))
+        else:
+            _check(lib().vors_trackers_create_on(int(device), C.byref(cfg), n_sequences, rows, cols, C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
