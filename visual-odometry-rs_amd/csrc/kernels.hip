@@ -15,6 +15,8 @@
 // Where fusing is harmless (accumulating the sums) explicit fmaf is used.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "device_common.h"
@@ -84,8 +86,126 @@ __global__ __launch_bounds__(256) void halve_mean_kernel(const uint8_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// mean pyramid, up to five halvings per launch: a wavefront owns a 32 x 128 tile of level 0 and everything above it (16 x 64 of level 1
+// ... 1 x 4 of level 5).  Level 0 is read once with 16-byte loads; every coarser level is written from registers and never read back from
+// memory (one level per launch moves 1.67 x the level-0 bytes, this 1.33 x).  Same arithmetic: ((a+b+c+d) as u16 / 4) as u8, and
+// halve's floor on odd sizes (multires.rs:67-88) means a pixel of level l only ever depends on pixels INSIDE level l-1.
+// ------------------------------------------------------------------------------------------------------------
+struct PyrLevels {
+    int n;                       // halvings done here (1..5)
+    int rows[7], cols[7];        // sizes of levels 0..n
+    int off[7];                  // offset of level l (>= 1) inside a pair's upper block
+};
+__device__ __forceinline__ uint32_t halve_words(uint32_t w0, uint32_t w1) {
+    // four pixels of two rows -> two means in bytes 0 and 2 (byte 1 is not clean: callers pick bytes).  v_perm_b32 spreads the even and
+    // the odd bytes of a word into 16-bit lanes (selector 0x0c = a zero byte).
+    const uint32_t s = __builtin_amdgcn_perm(0, w0, 0x0c020c00u) + __builtin_amdgcn_perm(0, w0, 0x0c030c01u) +
+                       __builtin_amdgcn_perm(0, w1, 0x0c020c00u) + __builtin_amdgcn_perm(0, w1, 0x0c030c01u);
+    return s >> 2;
+}
+__device__ __forceinline__ uint32_t pack_means(uint32_t lo, uint32_t hi) {
+    // bytes 0 and 2 of lo, then bytes 0 and 2 of hi
+    return __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+}
+__global__ __launch_bounds__(1024) void pyramid_fused_kernel(const uint8_t* __restrict__ level0, size_t stride0, uint8_t* __restrict__ upper,
+                                                             size_t upper_stride, PyrLevels lv, int tiles_x, int n_tiles, int wgs_per_image,
+                                                             int n_images) {
+    // A wavefront owns a tile on its own (no LDS, no barrier) as 8 x 8 lanes: a lane reads four rows x 16 pixels (all four 16-byte
+    // loads are issued before anything is used) and holds 2 x 8 of level 1 and 1 x 4 of level 2; the partner rows of the next
+    // halvings are 8, 16 and 32 lanes away.
+    // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md): all workgroups of an image go to ONE XCD, so that the pieces of
+    // a 128-byte line of the small levels, which come from several tiles, meet in that XCD's L2 instead of leaving as partial writes
+    // from several L2s.  Only speed depends on it.
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x >> 3;
+    const int image = (q / wgs_per_image) * 8 + (blockIdx.x & 7);
+    const int tile = (q % wgs_per_image) * (blockDim.x >> 6) + (threadIdx.x >> 6);  // a workgroup = one row of tiles when that fits
+    if (image >= n_images || tile >= n_tiles) return;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int rp = lane >> 3, cg = lane & 7;
+    const int ty = tyi * 32, x0 = txi * 128 + 16 * cg;
+    uint8_t* up = upper + (size_t)image * upper_stride;
+    const uint8_t* img = level0 + (size_t)image * stride0;
+    const int y0 = ty + 4 * rp;
+    const bool in_x = x0 < lv.cols[0];  // cols[0] % 16 == 0: a group is inside or outside as a whole
+    const bool in0 = in_x && y0 + 1 < lv.rows[0], in1 = in_x && y0 + 3 < lv.rows[0];
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+    const uint8_t* src = img + (uint32_t)(y0 * lv.cols[0] + x0);
+    if (in0) {
+        r0 = *reinterpret_cast<const uint4*>(src);
+        r1 = *reinterpret_cast<const uint4*>(src + lv.cols[0]);
+    }
+    if (in1) {
+        r2 = *reinterpret_cast<const uint4*>(src + 2 * lv.cols[0]);
+        r3 = *reinterpret_cast<const uint4*>(src + 3 * lv.cols[0]);
+    }
+    uint2 a0, a1;
+    a0.x = pack_means(halve_words(r0.x, r1.x), halve_words(r0.y, r1.y));
+    a0.y = pack_means(halve_words(r0.z, r1.z), halve_words(r0.w, r1.w));
+    a1.x = pack_means(halve_words(r2.x, r3.x), halve_words(r2.y, r3.y));
+    a1.y = pack_means(halve_words(r2.z, r3.z), halve_words(r2.w, r3.w));
+    uint8_t* d1 = up + lv.off[1] + (uint32_t)(((ty >> 1) + 2 * rp) * lv.cols[1] + (x0 >> 1));
+    if (in0) *reinterpret_cast<uint2*>(d1) = a0;
+    if (in1) *reinterpret_cast<uint2*>(d1 + lv.cols[1]) = a1;
+    if (lv.n < 2) return;
+    // level 2: a lane's own two rows; 8 pixels -> 4 (cols[2] % 4 == 0)
+    const uint32_t c = pack_means(halve_words(a0.x, a1.x), halve_words(a0.y, a1.y));
+    if (in1) *reinterpret_cast<uint32_t*>(up + lv.off[2] + (uint32_t)(((ty >> 2) + rp) * lv.cols[2] + (x0 >> 2))) = c;
+    if (lv.n < 3) return;
+    // level 3: rows (rp, rp + 1) for even rp; 4 pixels -> 2 (cols[3] % 2 == 0)
+    const uint32_t d = __builtin_amdgcn_perm(0, halve_words(c, __shfl_down(c, 8)), 0x0c0c0200u);
+    if ((rp & 1) == 0) {
+        const int y = (ty >> 3) + (rp >> 1), x = x0 >> 3;
+        if (y < lv.rows[3] && x < lv.cols[3]) *reinterpret_cast<uint16_t*>(up + lv.off[3] + (uint32_t)(y * lv.cols[3] + x)) = (uint16_t)d;
+    }
+    if (lv.n < 4) return;
+    // level 4: rows (rp, rp + 2) for rp % 4 == 0; 2 pixels -> 1 (v_sad_u8 against 0 adds the bytes of a word)
+    const uint32_t e = __builtin_amdgcn_sad_u8(d, 0, __builtin_amdgcn_sad_u8(__shfl_down(d, 16), 0, 0)) >> 2;
+    if ((rp & 3) == 0) {
+        const int y = (ty >> 4) + (rp >> 2), x = x0 >> 4;
+        if (y < lv.rows[4] && x < lv.cols[4]) up[lv.off[4] + (uint32_t)(y * lv.cols[4] + x)] = (uint8_t)e;
+    }
+    if (lv.n < 5) return;
+    // level 5: rows (0, 4) and the neighbouring group
+    const uint32_t s = e + __shfl_down(e, 32);
+    const uint32_t f = (s + __shfl_xor(s, 1)) >> 2;
+    if (rp == 0 && (cg & 1) == 0) {
+        const int y = ty >> 5, x = x0 >> 5;
+        if (y < lv.rows[5] && x < lv.cols[5]) up[lv.off[5] + (uint32_t)(y * lv.cols[5] + x)] = (uint8_t)f;
+    }
+}
+
+static int g_pyramid_fused = -1;  // VORS_PYRAMID_FUSED=0 keeps one level per launch (development aid)
+
 void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s) {
-    for (int l = 1; l < g.L; ++l) {
+    if (g_pyramid_fused < 0) {
+        const char* e = getenv("VORS_PYRAMID_FUSED");
+        g_pyramid_fused = (e && e[0] == '0') ? 0 : 1;
+    }
+    int first = 1;
+    if (g_pyramid_fused && g.L >= 2 && g.lv[0].cols % 16 == 0 && ((uintptr_t)pyr.level0) % 16 == 0 && g.S0 % 16 == 0 &&
+        ((uintptr_t)pyr.upper) % 16 == 0 && g.upper_stride % 16 == 0) {
+        PyrLevels lv{};
+        lv.n = std::min(g.L - 1, 5);
+        bool ok = true;
+        for (int l = 0; l <= lv.n; ++l) {
+            lv.rows[l] = g.lv[l].rows;
+            lv.cols[l] = g.lv[l].cols;
+            lv.off[l] = l ? g.lv[l].img_off : 0;
+            if (l && (g.lv[l].img_off < 0 || g.lv[l].img_off % 16 != 0)) ok = false;
+        }
+        if (ok) {
+            const int tiles_x = (g.lv[0].cols + 127) / 128, n_tiles = tiles_x * ((g.lv[0].rows + 31) / 32);
+            const int waves = tiles_x <= 16 ? tiles_x : 4;
+            const int wgs = (n_tiles + waves - 1) / waves;
+            dim3 grid((unsigned)(wgs * ((n_pairs + 7) / 8) * 8));
+            hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(64 * waves), 0, s, pyr.level0, (size_t)g.S0, pyr.upper, (size_t)g.upper_stride, lv,
+                               tiles_x, n_tiles, wgs, n_pairs);
+            first = lv.n + 1;
+        }
+    }
+    for (int l = first; l < g.L; ++l) {
         const LevelGeom& src = g.lv[l - 1];
         const LevelGeom& dst = g.lv[l];
         const uint8_t* sp = (l == 1) ? pyr.level0 : pyr.upper + src.img_off;
