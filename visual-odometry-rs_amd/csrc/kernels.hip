@@ -662,6 +662,75 @@ __global__ __launch_bounds__(256) void dense_idepth_level12_kernel(Geom g, const
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
     count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 2, n2);
 }
+// Levels 1, 2 AND 3 in one pass when rows(level 0) % 8 == 0 and cols(level 0) % 8 == 0: one thread per level-3 pixel takes its 8x8
+// depth block as two 4x8 halves (the body of the kernel above) and fuses their four level-2 pixels — level 2 is written once and not
+// read back by a halving launch (0.63 GB per 4096 pairs at 640x480).
+template <bool FAST>
+__global__ __launch_bounds__(256) void dense_idepth_level123_kernel(Geom g, const uint16_t* __restrict__ depth, Records rec) {
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cols3 = g.lv[3].cols;
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    if (t < g.lv[3].rows * cols3) {
+        const int y3 = t / cols3, x3 = t - y3 * cols3;
+        const int fc = g.lv[0].cols, c1 = g.lv[1].cols, c2 = g.lv[2].cols;
+        const size_t base = (size_t)pair * g.slots_total;
+        float od2[2][2], ov2[2][2];  // [row][col] of the 2x2 level-2 block
+        const uint16_t* p = depth + (size_t)pair * g.S0 + (size_t)(8 * y3) * fc + 8 * x3;
+        uint4 v8[8];  // all eight rows requested before any is used
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] = *reinterpret_cast<const uint4*>(p + (size_t)r * fc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t w[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint4 v = v8[4 * h + r];
+                w[r][0] = v.x;
+                w[r][1] = v.y;
+                w[r][2] = v.z;
+                w[r][3] = v.w;
+            }
+            float od1[2][4], ov1[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // children a=(2i,2j) b=(2i+1,2j) c=(2i,2j+1) d=(2i+1,2j+1)   (multires.rs:80-83)
+                    const uint32_t top = w[2 * i][j], bot = w[2 * i + 1][j];
+                    const uint32_t dz[4] = {top & 0xffffu, bot & 0xffffu, top >> 16, bot >> 16};
+                    fuse_depths<FAST>(g.depth_scale, g.idepth_variance, dz, &od1[i][j], &ov1[i][j], n0);
+                    n1 += ov1[i][j] >= 0.f;
+                }
+            const size_t s1 = base + g.lv[1].slot_off + (size_t)(4 * y3 + 2 * h) * c1 + 4 * x3;
+            *reinterpret_cast<float4*>(rec.IZ + s1) = make_float4(od1[0][0], od1[0][1], od1[0][2], od1[0][3]);
+            *reinterpret_cast<float4*>(rec.IZ + s1 + c1) = make_float4(od1[1][0], od1[1][1], od1[1][2], od1[1][3]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float dv[4] = {od1[0][2 * k], od1[1][2 * k], od1[0][2 * k + 1], od1[1][2 * k + 1]};
+                const float vv[4] = {ov1[0][2 * k], ov1[1][2 * k], ov1[0][2 * k + 1], ov1[1][2 * k + 1]};
+                fuse_dso_mean(dv, vv, &od2[h][k], &ov2[h][k]);
+                n2 += ov2[h][k] >= 0.f;
+            }
+            const size_t s2 = base + g.lv[2].slot_off + (size_t)(2 * y3 + h) * c2 + 2 * x3;
+            *reinterpret_cast<float2*>(rec.IZ + s2) = make_float2(od2[h][0], od2[h][1]);
+            *reinterpret_cast<float2*>(rec.V + s2) = make_float2(ov2[h][0], ov2[h][1]);
+        }
+        const float dv[4] = {od2[0][0], od2[1][0], od2[0][1], od2[1][1]};
+        const float vv[4] = {ov2[0][0], ov2[1][0], ov2[0][1], ov2[1][1]};
+        float od, ov;
+        fuse_dso_mean(dv, vv, &od, &ov);
+        n3 = ov >= 0.f;
+        const size_t s3 = base + g.lv[3].slot_off + t;
+        rec.IZ[s3] = od;
+        rec.V[s3] = ov;
+    }
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 0, n0);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 1, n1);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 2, n2);
+    count_add(rec.n_used + (size_t)pair * VORS_MAX_LEVELS + 3, n3);
+}
 __global__ __launch_bounds__(256) void dense_idepth_halve_kernel(Geom g, int l, Records rec) {
     const int pair = select_pair(g, blockIdx.y);
     if (pair < 0) return;
@@ -762,7 +831,12 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         if (g.L >= 2) {
             // (slots_total and slot_off are multiples of 4, so the vector stores of the wide kernels are aligned)
             const bool aligned = reinterpret_cast<uintptr_t>(depth) % 16 == 0;
-            if (g.L >= 3 && aligned && g.lv[0].rows % 4 == 0 && g.lv[0].cols % 16 == 0) {
+            if (g.L >= 4 && aligned && g.lv[0].rows % 8 == 0 && g.lv[0].cols % 8 == 0 && !getenv("VORS_IDEPTH_LEVEL12")) {
+                const dim3 grid((g.lv[3].n_slots + 255) / 256, n_pairs);
+                if (g.fast_idepth) hipLaunchKernelGGL(dense_idepth_level123_kernel<true>, grid, dim3(256), 0, s, g, depth, rec);
+                else hipLaunchKernelGGL(dense_idepth_level123_kernel<false>, grid, dim3(256), 0, s, g, depth, rec);
+                next = 4;
+            } else if (g.L >= 3 && aligned && g.lv[0].rows % 4 == 0 && g.lv[0].cols % 16 == 0) {
                 if (g.fast_idepth) hipLaunchKernelGGL(dense_idepth_level12_kernel<true>, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
                 else hipLaunchKernelGGL(dense_idepth_level12_kernel<false>, dim3((g.lv[2].n_slots / 2 + 255) / 256, n_pairs), dim3(256), 0, s, g, depth, rec);
                 next = 3;
