@@ -46,3 +46,39 @@ def test_every_pyramid_level_equals_the_oracle(rows, cols, L):
             for l in range(L):
                 assert (b.keyframe_image(p, l) == want_k[l]).all(), f"keyframe pair {p} level {l} unaligned={unaligned}"
                 assert (b.current_image(p, l) == want_c[l]).all(), f"current pair {p} level {l} unaligned={unaligned}"
+
+
+IDEPTH_SHAPES = [(64, 96, 4, ""), (128, 160, 5, ""), (128, 160, 5, "1"), (60, 80, 3, ""), (36, 64, 4, ""), (50, 72, 3, ""), (51, 77, 3, "")]
+
+
+@pytest.mark.parametrize("rows,cols,L,level12", IDEPTH_SHAPES, ids=[f"{c}x{r}_L{l}{'_level12' if e else ''}" for r, c, l, e in IDEPTH_SHAPES])
+def test_dense_inverse_depth_pyramid_bit_exact_on_every_path(rows, cols, L, level12, monkeypatch):
+    """Dense mode's inverse-depth pyramid (inverse_depth.rs:24-29,81-98) has four device forms by shape — levels 1-3 in one pass
+    (rows % 8 == 0, cols % 8 == 0, >= 4 levels), levels 1-2 in one pass (rows % 4 == 0, cols % 16 == 0; also behind
+    VORS_IDEPTH_LEVEL12=1), level 1 with wide loads (cols % 8 == 0) and the per-pixel form — and one halving kernel for the rest. Every
+    level of every form == the oracle tracker's points: coordinates, inverse depths and Jacobians bit for bit, with a third of the
+    depths unknown so that every child count occurs."""
+    import torch
+    if level12:
+        monkeypatch.setenv("VORS_IDEPTH_LEVEL12", level12)
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, cd, gt = O.synth_batch(2, rows, cols, seed0=0x5EEDAB00 + rows, intr=intr)
+    rng = np.random.default_rng(rows + cols)
+    kd[rng.random(kd.shape) < 0.33] = 0
+    kd[1, : rows // 2, : cols // 2] = 0   # whole blocks unknown at every level
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1)
+    b = V.Batch(cfg, 2, rows, cols)
+    poses = torch.zeros((2, 7), device="cuda"); status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    b.track_pairs(torch.from_numpy(kg).cuda(), torch.from_numpy(kd.view(np.int16)).cuda(), torch.from_numpy(cg).cuda(), poses, status)
+    torch.cuda.synchronize()
+    ocfg = O.make_config(L, intr, candidates_mode=1)
+    for p in range(2):
+        tr = O.Tracker(ocfg, 0.0, kd[p], 0.0, kg[p])
+        for l in range(L):
+            xy, iz, jac, tm = b.points(p, l)
+            oxy, oiz, ojac = tr.points(l)
+            assert xy.shape == oxy.shape, f"pair {p} level {l}: {len(xy)} vs {len(oxy)} points"
+            o1, o2 = np.lexsort((xy[:, 1], xy[:, 0])), np.lexsort((oxy[:, 1], oxy[:, 0]))
+            assert (xy[o1] == oxy[o2]).all()
+            assert (np.ascontiguousarray(iz[o1]).view(np.uint32) == np.ascontiguousarray(oiz[o2]).view(np.uint32)).all(), f"pair {p} level {l}"
+            assert (np.ascontiguousarray(jac[o1]).view(np.uint32) == np.ascontiguousarray(ojac[o2]).view(np.uint32)).all(), f"pair {p} level {l}"
