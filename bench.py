@@ -632,25 +632,29 @@ def main():
             # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
             # own batch of `pairs` pairs; the GPU overlaps the latency-bound tail of one step — straggler rounds, tree descent — with the
             # VALU-bound body of the next). `value` above stays the single-stream figure: its stage times and roofline are self-consistent.
+            # (vors_pipeline_*, the C ABI's throughput mode: a ring of two handles on internal streams; a second set of inputs and outputs so
+            # that consecutive steps share no buffer)
             w3 = Workload(V, args, args.candidates, device, seed0 + args.pairs)
-            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            pipe = V.Pipeline(main_w.cfg, args.pairs, args.rows, args.cols, depth=2)
             both = [main_w, w3]
 
             def alt(i):
-                with torch.cuda.stream(streams[i & 1]):
-                    both[i & 1].step()
+                w = both[i & 1]
+                pipe.submit(w.kg, w.kd, w.cg, w.poses, w.status, w.stats)
             for i in range(2 * max(args.warmup, 1)):
                 alt(i)
+            pipe.drain()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 alt(i)
+            pipe.drain()
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
             out["pipelined_two_streams"] = {"value": round(args.pairs * args.steps / dt3, 2), "unit": "frame-pairs/s",
                                             "ms_per_step": round(dt3 / args.steps * 1e3, 4),
-                                            "note": "steps alternate between two batch handles on two streams; not the headline"}
-            del w3
+                                            "note": "vors_pipeline_* with depth 2: steps alternate between two batch handles on two internal streams; not the headline"}
+            del pipe, w3
         if not args.no_sequences and not args.no_secondary:
             out["sequences_64"] = sequences_bench(V, args, device)
         if args.cpu_pairs != 0:

@@ -233,6 +233,27 @@ vors_status vors_batch_kernel_times(vors_batch* b, int stage, float* ms_out, int
 vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyframe_ms, float* pyramid_ms);
 void vors_batch_destroy(vors_batch* b);
 
+/* Throughput mode for a continuous feed of independent batches: a ring of `depth` batch handles, each on its own internal stream.
+ * The tail of a step is latency-bound (straggler rounds of the dense LM stage, the tree descent, the last workgroups of the per-pair
+ * kernel), its body VALU- or bandwidth-bound: with consecutive steps on different streams the GPU fills one with the other (depth 2 on
+ * one MI355X: +6 % dense, +12 % coarse-to-fine frame pairs per second; bench.py `pipelined_two_streams`). Every step is a plain
+ * vors_batch_track_pairs — same results bit for bit.
+ *   submit: the slot's stream first waits for everything enqueued on hip_stream so far (the inputs, and earlier readers of the output
+ *           buffers), then runs the step; nothing is synchronised. Buffers as for vors_batch_track_pairs, and they must stay valid
+ *           until the step has completed. *ticket (nullable) identifies the step.
+ *   wait:   host_sync = 0: hip_stream waits for the step (its outputs are then ordered on hip_stream); host_sync != 0: the calling
+ *           thread blocks until the step has completed.
+ *   drain:  the same for every step submitted so far.
+ * device < 0 = the calling thread's current device. */
+typedef struct vors_pipeline vors_pipeline;
+vors_status vors_pipeline_create(int device, const vors_config* cfg, int depth, int max_pairs, int rows, int cols, vors_pipeline** out);
+vors_status vors_pipeline_submit(vors_pipeline* p, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth,
+                                 const uint8_t* d_cur_gray, const float* d_prev_poses7 /* nullable */, float* d_out_poses7,
+                                 int32_t* d_out_status, vors_pair_stats* d_out_stats /* nullable */, void* hip_stream, int64_t* ticket);
+vors_status vors_pipeline_wait(vors_pipeline* p, int64_t ticket, void* hip_stream, int host_sync);
+vors_status vors_pipeline_drain(vors_pipeline* p, void* hip_stream, int host_sync);
+void vors_pipeline_destroy(vors_pipeline* p);
+
 /* Inspection of the keyframe data held by a batch handle (device -> host copies; tests and debugging).
  * level image (mean_pyramid, multires.rs:21-31), row-major rows_l x cols_l: */
 vors_status vors_batch_get_keyframe_image(vors_batch* b, int pair, int level, uint8_t* out, int* rows, int* cols);

@@ -951,6 +951,127 @@ void vors_tracker_destroy(vors_tracker* t) {
 // ---------------------------------------------------------------------------------------------------------------
 }  // extern "C"
 
+// ---------------------------------------------------------------------------------------------------------------
+// Throughput mode: a ring of batch handles, each with its own internal stream. A step's tail is latency-bound (straggler rounds of the
+// dense LM stage, the tree descent, the last workgroups of the per-pair kernel) and its body VALU- or bandwidth-bound; with the steps
+// of a continuous feed alternating between two handles on two streams the GPU fills one with the other.
+// ---------------------------------------------------------------------------------------------------------------
+struct vors_pipeline {
+    int device = 0, depth = 0;
+    std::vector<vors_batch*> slot;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> done;      // completion of the last step submitted to the slot
+    std::vector<long> ticket_of;       // ticket of that step (-1: none yet)
+    hipEvent_t ready = nullptr;        // "the caller's stream has reached the submit" (re-recorded per submit)
+    long next = 0;
+};
+static void pipeline_free(vors_pipeline* p) {
+    for (hipStream_t s : p->stream)
+        if (s) (void)hipStreamSynchronize(s);  // nothing may still be running on a handle that is about to go
+    for (vors_batch* b : p->slot) vors_batch_destroy(b);
+    for (hipStream_t s : p->stream)
+        if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : p->done)
+        if (e) (void)hipEventDestroy(e);
+    if (p->ready) (void)hipEventDestroy(p->ready);
+    delete p;
+}
+
+extern "C" {
+
+vors_status vors_pipeline_create(int device, const vors_config* cfg, int depth, int max_pairs, int rows, int cols, vors_pipeline** out) {
+    if (!out) return fail(VORS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (depth < 1 || depth > 8) return fail(VORS_ERR_INVALID_ARGUMENT, "depth must be 1..8");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) {
+            (void)hipGetLastError();
+            device = 0;
+        }
+    }
+    vors_pipeline* p = new vors_pipeline();
+    p->device = device;
+    p->depth = depth;
+    struct Guard {
+        vors_pipeline* p;
+        ~Guard() {
+            if (p) pipeline_free(p);
+        }
+    } cleanup{p};
+    for (int k = 0; k < depth; ++k) {
+        vors_batch* b = nullptr;
+        vors_status st = vors_batch_create_on(device, cfg, max_pairs, rows, cols, &b);
+        if (st != VORS_OK) return st;
+        p->slot.push_back(b);
+    }
+    DeviceGuard on_device(device);
+    if (!on_device.ok) return fail(VORS_ERR_HIP, "hipSetDevice failed");
+    for (int k = 0; k < depth; ++k) {
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        p->stream.push_back(s);
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->done.push_back(e);
+        p->ticket_of.push_back(-1);
+    }
+    HIP_TRY(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
+    cleanup.p = nullptr;
+    *out = p;
+    return VORS_OK;
+}
+
+vors_status vors_pipeline_submit(vors_pipeline* p, int n_pairs, const uint8_t* d_kf_gray, const uint16_t* d_kf_depth, const uint8_t* d_cur_gray,
+                                 const float* d_prev_poses7, float* d_out_poses7, int32_t* d_out_status, vors_pair_stats* d_out_stats,
+                                 void* hip_stream, int64_t* ticket) {
+    if (!p) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    DeviceGuard on_device(p->device);
+    const int k = (int)(p->next % p->depth);
+    vors_status st = check_stream(p->slot[k], static_cast<hipStream_t>(hip_stream));
+    if (st != VORS_OK) return st;
+    // the inputs (and the output buffers' previous readers) are ordered on the caller's stream: the slot's stream waits for it
+    HIP_TRY(hipEventRecord(p->ready, static_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(hipStreamWaitEvent(p->stream[k], p->ready, 0));
+    st = vors_batch_track_pairs(p->slot[k], n_pairs, d_kf_gray, d_kf_depth, d_cur_gray, d_prev_poses7, d_out_poses7, d_out_status, d_out_stats,
+                                p->stream[k]);
+    // (on failure part of the step may be enqueued: record the event all the same, so that wait / drain cover whatever runs)
+    HIP_TRY(hipEventRecord(p->done[k], p->stream[k]));
+    p->ticket_of[k] = p->next;
+    if (ticket) *ticket = p->next;
+    ++p->next;
+    return st;
+}
+
+vors_status vors_pipeline_wait(vors_pipeline* p, int64_t ticket, void* hip_stream, int host_sync) {
+    if (!p) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (ticket < 0 || ticket >= p->next) return fail(VORS_ERR_INVALID_ARGUMENT, "no such ticket");
+    DeviceGuard on_device(p->device);
+    const int k = (int)(ticket % p->depth);
+    // A slot's stream runs its steps in order: the event of a LATER step of the same slot covers this one too.
+    if (host_sync) HIP_TRY(hipEventSynchronize(p->done[k]));
+    else HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), p->done[k], 0));
+    return VORS_OK;
+}
+
+vors_status vors_pipeline_drain(vors_pipeline* p, void* hip_stream, int host_sync) {
+    if (!p) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL handle");
+    DeviceGuard on_device(p->device);
+    for (int k = 0; k < p->depth; ++k) {
+        if (p->ticket_of[k] < 0) continue;
+        if (host_sync) HIP_TRY(hipEventSynchronize(p->done[k]));
+        else HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), p->done[k], 0));
+    }
+    return VORS_OK;
+}
+
+void vors_pipeline_destroy(vors_pipeline* p) {
+    if (!p) return;
+    DeviceGuard on_device(p->device);
+    pipeline_free(p);
+}
+
+}  // extern "C"
+
 struct vors_trackers {
     vors_batch* batch = nullptr;
     int n_seq = 0;

@@ -106,6 +106,7 @@ EXPORTED_SYMBOLS = [
     "vors_trackers_create", "vors_trackers_create_on", "vors_trackers_count", "vors_trackers_init", "vors_trackers_track", "vors_trackers_state",
     "vors_trackers_current_frames", "vors_trackers_last_stats", "vors_trackers_enable_kernel_timing", "vors_trackers_kernel_times", "vors_trackers_destroy",
     "vors_synth_render_frames",
+    "vors_pipeline_create", "vors_pipeline_submit", "vors_pipeline_wait", "vors_pipeline_drain", "vors_pipeline_destroy",
 ]
 
 _lib = None
@@ -162,6 +163,12 @@ def lib():
         _lib.vors_trackers_destroy.restype = None
         _lib.vors_synth_render_frames.argtypes = [i, vp, vp, vp, i, i, vp, i, vp, vp, vp]
         _lib.vors_batch_track_pairs.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib.vors_pipeline_create.argtypes = [i, C.POINTER(vors_config), i, i, i, i, C.POINTER(vp)]
+        _lib.vors_pipeline_submit.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int64)]
+        _lib.vors_pipeline_wait.argtypes = [vp, C.c_int64, vp, i]
+        _lib.vors_pipeline_drain.argtypes = [vp, vp, i]
+        _lib.vors_pipeline_destroy.argtypes = [vp]
+        _lib.vors_pipeline_destroy.restype = None
         _lib.vors_batch_prepare_keyframes.argtypes = [vp, i, vp, vp, vp]
         _lib.vors_batch_track_current.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
         _lib.vors_batch_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -518,6 +525,47 @@ class Batch:
         _check(lib().vors_batch_get_points(self._h, pair, level, cap, _ptr(xy), _ptr(iz), _ptr(jac), _ptr(tm), C.byref(n)))
         n = n.value
         return xy[:n].copy(), iz[:n].copy(), jac[:n].copy(), tm[:n].copy()
+
+
+class Pipeline:
+    """vors_pipeline_*: a ring of `depth` batch handles on internal streams for a continuous feed of independent batches (throughput mode).
+    submit() orders the step after everything on torch's current stream and returns a ticket; wait() / drain() order torch's current
+    stream after the step(s) (host=True: block the calling thread instead). Results are those of Batch.track_pairs bit for bit."""
+
+    def __init__(self, config, max_pairs, rows, cols, depth=2, device=None):
+        self.config, self.max_pairs, self.rows, self.cols, self.depth = config, max_pairs, rows, cols, depth
+        self._h = C.c_void_p()
+        self._refs = {}
+        cfg = config.to_c()
+        _check(lib().vors_pipeline_create(-1 if device is None else int(device), C.byref(cfg), int(depth), max_pairs, rows, cols,
+                                          C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vors_pipeline_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def submit(self, kf_gray, kf_depth, cur_gray, out_poses7, out_status, out_stats=None, prev_poses7=None):
+        n = kf_gray.shape[0]
+        for t in (kf_gray, kf_depth, cur_gray):
+            if tuple(t.shape) != (n, self.rows, self.cols) or not t.is_contiguous() or n > self.max_pairs:
+                raise VorsError(f"expected contiguous [n <= {self.max_pairs}, {self.rows}, {self.cols}] images, got {tuple(t.shape)}")
+        ticket = C.c_int64(-1)
+        st = lib().vors_pipeline_submit(self._h, n, Batch._dp(kf_gray), Batch._dp(kf_depth), Batch._dp(cur_gray), Batch._dp(prev_poses7),
+                                        Batch._dp(out_poses7), Batch._dp(out_status), Batch._dp(out_stats), Batch._stream(), C.byref(ticket))
+        # the step reads and writes these buffers until it completes: keep them alive for as long as its slot can be running it
+        self._refs[ticket.value % self.depth] = (kf_gray, kf_depth, cur_gray, out_poses7, out_status, out_stats, prev_poses7)
+        _check(st)
+        return ticket.value
+
+    def wait(self, ticket, host=False):
+        _check(lib().vors_pipeline_wait(self._h, int(ticket), Batch._stream(), 1 if host else 0))
+
+    def drain(self, host=False):
+        _check(lib().vors_pipeline_drain(self._h, Batch._stream(), 1 if host else 0))
 
 
 class Trackers:
