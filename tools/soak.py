@@ -46,3 +46,20 @@ for mode in (0, 1, 2):
         del tr, gg, dd
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     print(f"mode {mode}: 40 trackers + 20 lock-step handles created / tracked / destroyed; free memory delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")
+
+# throughput-mode pipelines: create / feed / destroy with steps still in flight at destruction
+cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=1)
+kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED0000, 64, rows, cols, intr)
+for it in range(20):
+    pipe = V.Pipeline(cfg, 64, rows, cols, depth=2 + it % 2)
+    outs = [(torch.zeros((64, 7), device="cuda"), torch.zeros(64, dtype=torch.int32, device="cuda")) for _ in range(6)]
+    for k in range(6):
+        pipe.submit(kg, kd, cg, *outs[k])
+    if it % 2:
+        pipe.drain(host=True)
+    del pipe          # (even iterations: destroyed with work in flight - destroy must wait for it)
+    torch.cuda.synchronize()
+    assert all((o[0].cpu().numpy() == outs[0][0].cpu().numpy()).all() for o in outs)
+del kg, kd, cg, outs
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+print(f"pipelines: 20 x 6 steps; free memory delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")
