@@ -299,49 +299,42 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     // ---- top-down selection: level l -> l-1. Items = (root, node k, child c); the 4 children of a node sit in one quad.
     const uint32_t thresh = (uint32_t)g.thresh & 0xffffu;
     for (int l = L - 1; l >= 1; --l) {
-        const int cap = 1 << (L - 1 - l);
+        const int lc = L - 1 - l, cap = 1 << lc;  // (a power of two: slot arithmetic by shifts, not divisions)
         const int off = cap - 1, offc = 2 * cap - 1;
         const int items = KF_R * cap * 4;
         for (int base = 0; base < items; base += 64) {
             const int t = base + lane;
             const bool in = t < items;
-            const int rl = in ? (t >> 2) / cap : 0;  // root slot inside the wavefront
-            const int k = (t >> 2) - rl * cap, c = lane & 3;
+            const int rl = in ? (t >> 2) >> lc : 0;  // root slot inside the wavefront
+            const int k = (t >> 2) & (cap - 1), c = lane & 3;
             const uint32_t pxy = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
             const bool pvalid = pxy != VORS_INVALID_XY;
             const int cx = 2 * (int)(pxy & 0xffffu) + (c >> 1), cy = 2 * (int)(pxy >> 16) + (c & 1);
             int gx = 0, gy = 0, tm = 0;
             if (pvalid) grad_tmpl_at(g, kf0, kfu, pair, l - 1, cx, cy, &gx, &gy, &tm);
             const uint32_t g2 = (uint32_t)(gx * gx + gy * gy) & 0xffffu;  // `as u16` wrap, gradient.rs:39-43
-            uint32_t v[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = (uint32_t)__shfl((int)g2, (lane & ~3) + m);
-            int rk[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                int r = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r += (v[j] < v[m] || (v[j] == v[m] && j < m)) ? 1 : 0;
-                rk[m] = r;
+            // The four children of a node sit in one quad. Stable ranking (a later child wins a tie: ties rank by child index) = ranking
+            // of the DISTINCT keys (g2 << 2 | child); the quad's keys by DPP quad broadcasts, sorted by a 5-exchange network.
+            const uint32_t key = (g2 << 2) | (uint32_t)c;
+            uint32_t k0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x00, 0xf, 0xf, true);
+            uint32_t k1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x55, 0xf, 0xf, true);
+            uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xaa, 0xf, 0xf, true);
+            uint32_t k3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xff, 0xf, 0xf, true);
+            {
+                uint32_t lo, hi;
+                lo = min(k0, k1); hi = max(k0, k1); k0 = lo; k1 = hi;
+                lo = min(k2, k3); hi = max(k2, k3); k2 = lo; k3 = hi;
+                lo = min(k0, k2); hi = max(k0, k2); k0 = lo; k2 = hi;
+                lo = min(k1, k3); hi = max(k1, k3); k1 = lo; k3 = hi;
+                lo = min(k1, k2); hi = max(k1, k2); k1 = lo; k2 = hi;
             }
-            uint32_t second = 0, third = 0;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (rk[m] == 2) second = v[m];
-                if (rk[m] == 1) third = v[m];
-            }
-            const bool keep2 = second > ((third + thresh) & 0xffffu);  // u16 wrapping add, coarse_to_fine.rs:85
-            const int myrank = rk[c];
-            if (in) {
-                const uint32_t cxy = (uint32_t)cx | ((uint32_t)cy << 16);
-                const uint32_t cg = slim_pack_tg(tm, gx, gy);
-                if (myrank == 3) {
-                    xy[rl * NODES + offc + 2 * k] = pvalid ? cxy : VORS_INVALID_XY;
-                    gr[rl * NODES + offc + 2 * k] = cg;
-                } else if (myrank == 2) {
-                    xy[rl * NODES + offc + 2 * k + 1] = (pvalid && keep2) ? cxy : VORS_INVALID_XY;
-                    gr[rl * NODES + offc + 2 * k + 1] = cg;
-                }
+            const uint32_t second = k2 >> 2, third = k1 >> 2;                 // the values of rank 2 and rank 1
+            const bool keep2 = second > ((third + thresh) & 0xffffu);         // u16 wrapping add, coarse_to_fine.rs:85
+            if (in && key >= k2) {  // rank 3 (the best: always kept) -> slot 2k, rank 2 (kept if it stands out) -> slot 2k + 1
+                const bool best = key == k3;
+                const int dst = rl * NODES + offc + 2 * k + (best ? 0 : 1);
+                xy[dst] = (pvalid && (best || keep2)) ? ((uint32_t)cx | ((uint32_t)cy << 16)) : VORS_INVALID_XY;
+                gr[dst] = slim_pack_tg(tm, gx, gy);
             }
         }
         kf_wave_sync();
@@ -351,7 +344,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     {
         const int cap = 1 << (L - 1), off = cap - 1;
         for (int t = lane; t < KF_R * cap; t += 64) {
-            const int rl = t / cap, k = t - rl * cap;
+            const int rl = t >> (L - 1), k = t & (cap - 1);
             const uint32_t p = xy[rl * NODES + off + k];
             if (p != VORS_INVALID_XY) {
                 const uint16_t dz = depth[(size_t)pair * g.S0 + (size_t)(p >> 16) * g.lv[0].cols + (p & 0xffffu)];
@@ -370,7 +363,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
         const int cap = 1 << (L - 1 - l);
         const int off = cap - 1, offc = 2 * cap - 1;
         for (int t = lane; t < KF_R * cap; t += 64) {
-            const int rl = t / cap, k = t - rl * cap;
+            const int rl = t >> (L - 1 - l), k = t & (cap - 1);
             const int c1 = rl * NODES + offc + 2 * k, c2 = c1 + 1, dst = rl * NODES + off + k;
             const bool k1 = xy[c1] != VORS_INVALID_XY, k2 = xy[c2] != VORS_INVALID_XY;
             if (k1 && k2) {
@@ -399,7 +392,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
         int filled = 0;  // wavefront-uniform running count of points written
         for (int base = 0; base < n_here; base += 64) {
             const int t = base + lane;
-            const int rl = t / cap, k = t - rl * cap;
+            const int rl = t >> (L - 1 - l), k = t & (cap - 1);
             const bool in = t < n_here;
             const uint32_t p = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
             const bool valid = p != VORS_INVALID_XY;
