@@ -51,20 +51,25 @@ __device__ __forceinline__ void grad_at(const Geom& g, const uint8_t* level0, co
 // the block gradient reads (multires.rs:21-31), at l == 0 the centre pixel is one more load issued with the four neighbours.
 __device__ __forceinline__ void grad_tmpl_at(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l, int x,
                                              int y, int* gx, int* gy, int* tm) {
+    // (32-bit lane offsets from a wavefront-uniform base: the loads take the scalar-base + vector-offset form, no 64-bit lane arithmetic)
     if (l == 0) {
         const int rows = g.lv[0].rows, cols = g.lv[0].cols;
-        const uint8_t* p = level0 + (size_t)pair * g.S0 + (size_t)y * cols + x;
+        const uint8_t* p = level0 + (size_t)pair * g.S0;
+        const unsigned o = (unsigned)(y * cols + x);
         const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
-        const int l0 = p[interior ? -1 : 0], r0 = p[interior ? 1 : 0], u0 = p[interior ? -cols : 0], d0 = p[interior ? cols : 0];
-        *tm = p[0];
+        const unsigned dx = interior ? 1u : 0u, dy = interior ? (unsigned)cols : 0u;
+        const int l0 = p[o - dx], r0 = p[o + dx], u0 = p[o - dy], d0 = p[o + dy];
+        *tm = p[o];
         *gx = (r0 - l0) / 2;  // borders: the taps alias the centre pixel -> 0, like gradient.rs:15-33
         *gy = (d0 - u0) / 2;
     } else {
         const int fc = g.lv[l - 1].cols;
-        const uint8_t* p = level_ptr(g, level0, upper, pair, l - 1) + (size_t)(2 * y) * fc + 2 * x;
+        const uint8_t* pb = level_ptr(g, level0, upper, pair, l - 1);
+        const unsigned o = (unsigned)((2 * y) * fc + 2 * x);
+        const uint8_t* p = pb + o;
         uint16_t r0, r1;  // the 2x2 block as two (possibly unaligned) 16-bit loads instead of four byte loads
         __builtin_memcpy(&r0, p, 2);
-        __builtin_memcpy(&r1, p + fc, 2);
+        __builtin_memcpy(&r1, pb + (o + (unsigned)fc), 2);
         const int a = r0 & 0xff, c = r0 >> 8, b = r1 & 0xff, d = r1 >> 8;
         *gx = (c + d - a - b) / 2;
         *gy = (b - a + d - c) / 2;

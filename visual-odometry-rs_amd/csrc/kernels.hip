@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             const int rl = t >> (L - 1), k = t & (cap - 1);
             const uint32_t p = xy[rl * NODES + off + k];
             if (p != VORS_INVALID_XY) {
-                const uint16_t dz = depth[(size_t)pair * g.S0 + (size_t)(p >> 16) * g.lv[0].cols + (p & 0xffffu)];
+                const uint16_t dz = (depth + (size_t)pair * g.S0)[(p >> 16) * (unsigned)g.lv[0].cols + (p & 0xffffu)];  // uniform base + 32-bit offset
                 if (dz == 0) {
                     xy[rl * NODES + off + k] = VORS_INVALID_XY;
                 } else {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
             const bool valid = p != VORS_INVALID_XY;
             const unsigned long long m = __ballot(valid);
             const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (valid) out[filled + before] = SlimRec{p, sd[rl * NODES + off + k], gr[rl * NODES + off + k]};
+            if (valid) out[(unsigned)(filled + before)] = SlimRec{p, sd[rl * NODES + off + k], gr[rl * NODES + off + k]};
             filled += __popcll(m);
         }
         if (lane == 0) rec.region_cnt[((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions + region] = filled;
