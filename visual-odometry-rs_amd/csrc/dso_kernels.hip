@@ -525,7 +525,12 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
     } else {
         hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
     }
-    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(1024), 0, s, g, ws, out);
+    // Threads per pair: the kernel is a chain of short phases over planes in global memory with a barrier between them; a large batch
+    // runs faster with more, smaller workgroups per CU to interleave (4096 pairs: 1.17 -> 1.02 ms with 512 threads), a small one with
+    // the shortest chain per pair (<= 1024 pairs: 1024 threads win by 2-20 %). Results do not depend on it.
+    static const int forced = getenv("VORS_DSO_ROUNDS_THREADS") ? atoi(getenv("VORS_DSO_ROUNDS_THREADS")) : 0;
+    const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 2048 ? 512 : 1024);
+    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out);
 }
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
