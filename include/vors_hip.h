@@ -192,6 +192,7 @@ typedef struct vors_batch vors_batch;
  *   VORS_DSO_SCAN=1              DSO mode: the usable picks from a pass over the stamp plane instead of the selection rounds' own list
  *                                (identical lists)
  *   VORS_DSO_ROUNDS_THREADS=n    DSO mode: threads per pair in the selection-rounds kernel (default 512 from 2048 pairs on, else 1024)
+ *   VORS_DSO_RECORDS_THREADS=512|1024  DSO mode: threads per pair in the sparse records kernel (default 512 from 512 pairs on, else 1024)
  *   VORS_PYRAMID_FUSED=0         mean pyramid one level per launch instead of up to five halvings in one (bit-identical; read once per process)
  *   VORS_IDEPTH_LEVEL12=1        dense mode: inverse-depth levels 1-2 in one pass + a halving launch instead of levels 1-3 in one (bit-identical)
  *   VORS_FUSED_EXACT_POINTS=n    FUSED arithmetic: levels of at most n points are evaluated in the EXACT arithmetic (default 2500; 0 = the

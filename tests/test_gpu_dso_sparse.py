@@ -36,11 +36,13 @@ np.savez(out, **res)
 """
 
 
-def run(tmp_path, tag, planes, rows, cols, L, scan=False):
+def run(tmp_path, tag, planes, rows, cols, L, scan=False, threads=None):
     out = str(tmp_path / f"{tag}.npz")
     env = dict(os.environ)
     env["VORS_DSO_PLANES"] = "1" if planes else "0"
     env["VORS_DSO_SCAN"] = "1" if scan else "0"
+    if threads:
+        env["VORS_DSO_ROUNDS_THREADS"], env["VORS_DSO_RECORDS_THREADS"] = str(threads[0]), str(threads[1])
     subprocess.run([sys.executable, "-c", DUMP.format(root=ROOT, rows=rows, cols=cols, L=L, out=out)], check=True, env=env, timeout=300)
     return np.load(out)
 
@@ -67,5 +69,15 @@ def test_pick_list_of_the_selection_rounds_equals_the_scan_of_the_stamp_plane(tm
     VORS_DSO_SCAN=1 still extracts them with mask_sparse_scan_kernel. Both feed the same sort: identical lists, hence identical POSES
     bit for bit (incl. the shape whose list overflows and goes through in groups of bands)."""
     a, b = run(tmp_path, "list", False, rows, cols, L), run(tmp_path, "scan", False, rows, cols, L, scan=True)
+    for key in a.files:
+        assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key
+
+
+@pytest.mark.parametrize("rows,cols,L", [(480, 640, 6), (121, 163, 4), (64, 96, 2)])
+def test_threads_per_pair_of_the_selector_and_records_kernels_do_not_change_the_lists(tmp_path, rows, cols, L):
+    """Large batches run the selection rounds and the records kernel with 512 threads per pair, small ones with 1024 (scheduling only):
+    same candidates, same values, same order, hence the same poses bit for bit."""
+    a = run(tmp_path, "t1024", False, rows, cols, L, threads=(1024, 1024))
+    b = run(tmp_path, "t512", False, rows, cols, L, threads=(512, 512))
     for key in a.files:
         assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key

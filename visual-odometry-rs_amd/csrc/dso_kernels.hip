@@ -528,7 +528,8 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
     // Threads per pair: the kernel is a chain of short phases over planes in global memory with a barrier between them; a large batch
     // runs faster with more, smaller workgroups per CU to interleave (4096 pairs: 1.17 -> 1.02 ms with 512 threads), a small one with
     // the shortest chain per pair (<= 1024 pairs: 1024 threads win by 2-20 %). Results do not depend on it.
-    static const int forced = getenv("VORS_DSO_ROUNDS_THREADS") ? atoi(getenv("VORS_DSO_ROUNDS_THREADS")) : 0;
+    const char* e = getenv("VORS_DSO_ROUNDS_THREADS");
+    const int forced = e ? atoi(e) : 0;
     const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 2048 ? 512 : 1024);
     hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out);
 }
@@ -872,8 +873,9 @@ __device__ __forceinline__ uint32_t morton_compact(uint32_t k) {
     return k;
 }
 constexpr int SPARSE_LDS_N = 4096;  // entries of the LDS form: 48 KB (sort words, then key / inverse depth / weight in their place): three workgroups per CU
-// Exclusive position of a flagged thread among the flagged threads of the workgroup (1024 threads), plus their number.
+// Exclusive position of a flagged thread among the flagged threads of the workgroup (T threads), plus their number.
 // Two barriers; `s_wave` is workgroup scratch.
+template <int T>
 __device__ __forceinline__ int block_rank(bool flag, int* s_wave, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long bal = __ballot(flag);
@@ -883,7 +885,7 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_wave, int* total) {
     __syncthreads();
     int pos = before, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < T / 64; ++w) {
         pos += w < wave ? s_wave[w] : 0;
         tot += s_wave[w];
     }
@@ -900,8 +902,9 @@ struct SparseScan {
     int from_stamps, cols0, cap_n;
     bool vec;
 };
+template <int T>
 __device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1, int* s_n) {
-    for (int t0 = p0 + (int)threadIdx.x * 16; t0 < p1; t0 += 1024 * 16) {
+    for (int t0 = p0 + (int)threadIdx.x * 16; t0 < p1; t0 += T * 16) {
         uint32_t bits = 0;
         if (q.vec) {
             const uint4 pk = *reinterpret_cast<const uint4*>(q.src + t0);
@@ -943,6 +946,7 @@ __device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1,
 }
 // Phases B-D on n0 appended words. `a` (sort words) and `key` (three arrays of `cap_set`) are EITHER the LDS buffers OR the pair's global
 // scratch; the function is inlined once per case so that the LDS case compiles to ds_ instructions (not flat ones).
+template <int T>
 __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, const uint8_t* kfu, int pair, const uint64_t* gsort, int n0,
                                              uint64_t* a, bool copy_in, uint32_t* key, int cap_set, const Records& rec, int* s_wave, int* s_out,
                                              uint32_t* s_prev) {
@@ -950,13 +954,13 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
     int P = 2;
     while (P < n0) P <<= 1;
     if (copy_in)
-        for (int i = tid; i < P; i += 1024) a[i] = i < n0 ? gsort[i] : ~0ull;
+        for (int i = tid; i < P; i += T) a[i] = i < n0 ? gsort[i] : ~0ull;
     else
-        for (int i = n0 + tid; i < P; i += 1024) a[i] = ~0ull;
+        for (int i = n0 + tid; i < P; i += T) a[i] = ~0ull;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += 1024) {
+            for (int i = tid; i < P; i += T) {
                 const int q = i ^ j;
                 if (q > i) {
                     const uint64_t x = a[i], y = a[q];
@@ -973,13 +977,13 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
     float* dd = reinterpret_cast<float*>(key + cap_set);
     float* vv = reinterpret_cast<float*>(key + 2 * cap_set);
     if (copy_in) {  // LDS form: the arrays take the place of the sorted words (n0 <= 4096: four words per thread through registers)
-        uint64_t c[SPARSE_LDS_N / 1024];
+        uint64_t c[SPARSE_LDS_N / T];
 #pragma unroll
-        for (int q = 0; q < SPARSE_LDS_N / 1024; ++q) c[q] = tid + 1024 * q < n0 ? a[tid + 1024 * q] : 0ull;
+        for (int q = 0; q < SPARSE_LDS_N / T; ++q) c[q] = tid + T * q < n0 ? a[tid + T * q] : 0ull;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < SPARSE_LDS_N / 1024; ++q) {
-            const int i = tid + 1024 * q;
+        for (int q = 0; q < SPARSE_LDS_N / T; ++q) {
+            const int i = tid + T * q;
             if (i < n0) {
                 key[i] = (uint32_t)(c[q] >> 16);
                 dd[i] = g.depth_scale / (float)(uint32_t)(c[q] & 0xffffu);  // from_depth, inverse_depth.rs:24-29
@@ -987,7 +991,7 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
             }
         }
     } else {
-        for (int i = tid; i < n0; i += 1024) {
+        for (int i = tid; i < n0; i += T) {
             const uint64_t c = a[i];
             key[i] = (uint32_t)(c >> 16);
             dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);
@@ -1002,7 +1006,7 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
             int n_new = 0;
             if (tid == 0) *s_prev = 0xffffffffu;
             __syncthreads();
-            for (int base = 0; base < n; base += 1024) {
+            for (int base = 0; base < n; base += T) {
                 const int i = base + tid;
                 bool head = false;
                 uint32_t pk = 0;
@@ -1036,8 +1040,8 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
                     }
                 }
                 int total;
-                const int pos = n_new + block_rank(head, s_wave, &total);  // (its barriers separate this chunk's reads from its writes)
-                if (i < n && (tid == 1023 || i == n - 1)) *s_prev = pk;
+                const int pos = n_new + block_rank<T>(head, s_wave, &total);  // (its barriers separate this chunk's reads from its writes)
+                if (i < n && (tid == T - 1 || i == n - 1)) *s_prev = pk;
                 if (head) {
                     key[pos] = pk;
                     dd[pos] = fd;
@@ -1051,7 +1055,7 @@ __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, 
         // records of level l (engine.h SlimRec), appended behind those of the earlier groups of bands
         const int cap = g.lv[l].n_slots, o0 = s_out[l], n_out = max(0, min(n, cap - o0));
         SlimRec* out = rec.S + (size_t)pair * g.slots_total + g.lv[l].slot_off + o0;
-        for (int i = tid; i < n_out; i += 1024) {
+        for (int i = tid; i < n_out; i += T) {
             const uint32_t k2 = key[i];
             const int x = (int)morton_compact(k2 >> 1), y = (int)morton_compact(k2);
             int gx, gy, tm;
@@ -1176,7 +1180,8 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
     }
 }
 #undef SCAN_T0
-__global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+template <int T>
+__global__ __launch_bounds__(T) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                     const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
                                                                     int from_stamps, PixelPlanes pp, Records rec, int cap_n) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_set[3 * SPARSE_LDS_N];  // 48 KB: the sort words first (32 KB), then the three arrays in their place
@@ -1222,7 +1227,7 @@ __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const
         } else {
             const int first = band;
             for (; band < n_bands; ++band) {
-                sparse_scan(q, band * band_rows * cols0, min(S0, (band + 1) * band_rows * cols0), &s_n);
+                sparse_scan<T>(q, band * band_rows * cols0, min(S0, (band + 1) * band_rows * cols0), &s_n);
                 __syncthreads();
                 const int n_now = s_n;
                 __syncthreads();
@@ -1236,9 +1241,9 @@ __global__ __launch_bounds__(1024) void mask_sparse_records_kernel(Geom g, const
         }
         if (n0 == 0) continue;
         if (n0 <= SPARSE_LDS_N)
-            sparse_flush(g, kf0, kfu, pair, gsort, n0, lds_sort, true, lds_set, SPARSE_LDS_N, rec, s_wave, s_out, &s_prev);
+            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, lds_sort, true, lds_set, SPARSE_LDS_N, rec, s_wave, s_out, &s_prev);
         else
-            sparse_flush(g, kf0, kfu, pair, gsort, n0, gsort, false, gset, cap_n, rec, s_wave, s_out, &s_prev);
+            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, gsort, false, gset, cap_n, rec, s_wave, s_out, &s_prev);
     }
     __syncthreads();
     if (tid < g.L) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + tid] = s_out[tid];
@@ -1266,7 +1271,15 @@ void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs
             launch_dso_selection(g, kf, ws, n_pairs, s,
                                  DsoListOut{depth, reinterpret_cast<uint64_t*>(pp.v), (size_t)pp.stride / 2, pp.counts, pp.chunks_total, cap_n});
         }
-        hipLaunchKernelGGL(mask_sparse_records_kernel, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
+        // Threads per pair of the records kernel (48 KB of LDS per workgroup): 512 from 512 pairs on — three workgroups per CU instead of
+        // two, 1.09 -> 0.60 ms per 4096 pairs; a small batch is faster with 1024 (the shortest chain per pair). Same lists either way.
+        const char* e = getenv("VORS_DSO_RECORDS_THREADS");
+        const int forced = e ? atoi(e) : 0;
+        const int rt = (forced == 512 || forced == 1024) ? forced : (n_pairs >= 512 ? 512 : 1024);
+        if (rt == 512)
+            hipLaunchKernelGGL(mask_sparse_records_kernel<512>, dim3(n_pairs), dim3(512), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
+        else
+            hipLaunchKernelGGL(mask_sparse_records_kernel<1024>, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
         return;
     }
     launch_dso_selection(g, kf, ws, n_pairs, s);
