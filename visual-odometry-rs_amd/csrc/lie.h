@@ -218,10 +218,21 @@ VORS_HD float div_uniform(float x, const FastDiv& f) {
     }
     return x / f.d;
 }
+// The same with the choice made at run time (`ok` is uniform over a level: one scalar branch), for code that has no template to spare.
+VORS_HD float div_uniform_rt(float x, const FastDiv& f) {
+    return f.ok ? div_uniform<true>(x, f) : x / f.d;
+}
 struct IntrFast {
     Intr k;
     FastDiv fu, fv;
 };
+// back_project / warp_jacobian_at with the three divisions by the focal lengths through div_uniform_rt (bit-identical by construction).
+VORS_HD V3 back_project_rt(const IntrFast& kf, float px, float py, float depth) {
+    const float z = depth;
+    const float y = div_uniform_rt((py - kf.k.cv) * z, kf.fv);
+    const float x = div_uniform_rt((px - kf.k.cu) * z - kf.k.skew * y, kf.fu);
+    return V3{x, y, z};
+}
 // back_project with the two divisions by fv / fu through div_uniform (bit-identical to back_project by construction).
 template <bool FAST>
 VORS_HD V3 back_project_fast(const IntrFast& kf, float px, float py, float depth) {
@@ -244,6 +255,20 @@ VORS_HD void warp_jacobian_at_fast(float gu, float gv, float u, float v, float _
     J[3] = gu * (-a * b * _fv - k.skew) + gv * (-b * b * _fv - k.fv);
     J[4] = gu * (a * c * _fuv + k.fu) + gv * (b * c * _fuv);
     J[5] = gu * (-k.fu * k.fu * b + k.skew * c) * _fuv + gv * div_uniform<FAST>(c, kf.fu);
+}
+VORS_HD void warp_jacobian_at_rt(float gu, float gv, float u, float v, float _z, const IntrFast& kf, float J[6]) {
+    const Intr& k = kf.k;
+    const float a = u - k.cu;
+    const float b = v - k.cv;
+    const float c = a * k.fv - k.skew * b;
+    const float _fv = 1.0f / k.fv;
+    const float _fuv = 1.0f / (k.fu * k.fv);
+    J[0] = gu * _z * k.fu;
+    J[1] = _z * (gu * k.skew + gv * k.fv);
+    J[2] = -_z * (gu * a + gv * b);
+    J[3] = gu * (-a * b * _fv - k.skew) + gv * (-b * b * _fv - k.fv);
+    J[4] = gu * (a * c * _fuv + k.fu) + gv * (b * c * _fuv);
+    J[5] = gu * (-k.fu * k.fu * b + k.skew * c) * _fuv + gv * div_uniform_rt(c, kf.fu);
 }
 
 // so3 / se3 log: API parity only (src/math/so3.rs:81-99, src/math/se3.rs:99-129); host use.

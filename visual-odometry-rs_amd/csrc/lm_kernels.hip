@@ -142,6 +142,7 @@ struct SlimSrc {
     static constexpr bool SKIP_EMPTY = false;
     const SlimRec* S;
     Intr k;
+    FastDiv fu, fv;  // the focal lengths as verified fast divisors (lie.h div_uniform; `ok` = 0: IEEE division)
     struct Raw {
         SlimRec r[2];
         bool valid[2];
@@ -169,13 +170,13 @@ struct SlimSrc {
     __device__ __forceinline__ void positions(const Raw& r, Pos p[2]) const {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const V3 P = back_project(k, (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16), 1.0f / r.r[g].iz);
+            const V3 P = back_project_rt(IntrFast{k, fu, fv}, (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16), 1.0f / r.r[g].iz);
             p[g] = Pos{P.x, P.y, P.z, r.valid[g] ? (float)(r.r[g].tg & 0xff) : -1.0f};
         }
     }
     __device__ __forceinline__ void jacobian(const Raw& r, int g, float J[6]) const {
-        warp_jacobian_at((float)slim_gx(r.r[g].tg), (float)slim_gy(r.r[g].tg), (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16),
-                         r.r[g].iz, k, J);
+        warp_jacobian_at_rt((float)slim_gx(r.r[g].tg), (float)slim_gy(r.r[g].tg), (float)(r.r[g].xy & 0xffffu), (float)(r.r[g].xy >> 16),
+                            r.r[g].iz, IntrFast{k, fu, fv}, J);
     }
     __device__ __forceinline__ int slot(const Raw&, int, int) const { return -1; }
 };
@@ -1439,10 +1440,10 @@ __device__ __forceinline__ void with_level_source(const Geom& g, int lvl, int pa
         const SlimRec* S = rec.S + (size_t)pair * g.slots_total + lg.slot_off;
         const int n = __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]);
         if constexpr (FUSED) {
-            FusedSlimSrc src{{S, lg.k}};
+            FusedSlimSrc src{{S, lg.k, lg.fu, lg.fv}};
             f(src, n);
         } else {
-            SlimSrc src{S, lg.k};
+            SlimSrc src{S, lg.k, lg.fu, lg.fv};
             f(src, n);
         }
     }
