@@ -1,3 +1,5 @@
+"""Development aid (run through gpurun): handle churn — batch handles, pipelines, batches on fresh streams — and the free device memory after
+every 20: it must plateau (the HIP runtime keeps per-queue scratch; the handles themselves return everything)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
