@@ -630,7 +630,7 @@ def main():
                     parity_secondary = parity_block(args, w2, n_par)
                 del w2
             # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
-            # own batch of `pairs` pairs; the GPU overlaps the latency-bound tail of one step — straggler rounds, tree descent — with the
+            # own batch of `pairs` pairs; the GPU overlaps the tail of one step — dependent straggler rounds, last workgroups of per-pair kernels — with the
             # VALU-bound body of the next). `value` above stays the single-stream figure: its stage times and roofline are self-consistent.
             # (vors_pipeline_*, the C ABI's throughput mode: a ring of two handles on internal streams; a second set of inputs and outputs so
             # that consecutive steps share no buffer)

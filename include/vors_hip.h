@@ -236,7 +236,7 @@ vors_status vors_batch_last_kernel_ms(vors_batch* b, float* lm_ms, float* keyfra
 void vors_batch_destroy(vors_batch* b);
 
 /* Throughput mode for a continuous feed of independent batches: a ring of `depth` batch handles, each on its own internal stream.
- * The tail of a step is latency-bound (straggler rounds of the dense LM stage, the tree descent, the last workgroups of the per-pair
+ * The tail of a step leaves the GPU partly idle (dependent straggler rounds of the dense LM stage, the last workgroups of the per-pair
  * kernel), its body VALU- or bandwidth-bound: with consecutive steps on different streams the GPU fills one with the other (depth 2 on
  * one MI355X: +6 % dense, +12 % coarse-to-fine frame pairs per second; bench.py `pipelined_two_streams`). Every step is a plain
  * vors_batch_track_pairs — same results bit for bit.
