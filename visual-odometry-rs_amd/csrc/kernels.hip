@@ -414,9 +414,12 @@ __global__ __launch_bounds__(256) void compact_regions_kernel(Geom g, Records re
     const int pair = select_pair(g, blockIdx.y);
     if (pair < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // all levels of a pair in one workgroup, finest (largest) first: a sixth of the workgroups of a (level, pair) grid, whose small
-    // levels were nothing but dispatch (24,576 workgroups at 4096 pairs: 0.26 ms)
-    for (int l = 0; l < g.L; ++l) {
+    // Large batches: all levels of a pair in one workgroup, finest (largest) first — a sixth of the workgroups of a (level, pair) grid, whose
+    // small levels were nothing but dispatch (24,576 workgroups at 4096 pairs: 0.26 ms). Small batches and the masked launches of the
+    // lock-step trackers (a handful of promoted sequences per frame): one workgroup per (level, pair), gridDim.x = L — the six levels of a
+    // pair are a chain of dependent barriers and copies, 32 us in one workgroup, and nothing else is running meanwhile.
+    const int l_first = gridDim.x > 1 ? (int)blockIdx.x : 0, l_end = gridDim.x > 1 ? l_first + 1 : g.L;
+    for (int l = l_first; l < l_end; ++l) {
         const int cap_r = rec.kf_r << (g.L - 1 - l);  // slots per region at this level
         const int* cnt = rec.region_cnt + ((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions;
         const size_t lvl0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
@@ -852,7 +855,7 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else if (r == 2) hipLaunchKernelGGL(keyframe_sparse_kernel<2>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else hipLaunchKernelGGL(keyframe_sparse_kernel<1>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
-        hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_pairs), dim3(256), 0, s, g, rec);
+        hipLaunchKernelGGL(compact_regions_kernel, dim3(n_pairs <= 1024 ? g.L : 1, n_pairs), dim3(256), 0, s, g, rec);
     }
 }
 
