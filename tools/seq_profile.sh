@@ -33,14 +33,14 @@ poses, status, kf = t.current_frames()
 print(f"$MODE: {n * (F - 1) / dt:.0f} frames/s, {dt / (F - 1) * 1e3:.3f} ms per lock-step frame, keyframes now at frame indices {sorted(set(kf.tolist()))[:8]}...")
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o seq -- python $OUT/run.py > $OUT/run.log 2>&1
-tail -1 $OUT/run.log
+grep "frames/s" $OUT/run.log
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 with open("$OUT/kernel_stats.md", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats: 64 lock-step sequences x 39 tracked frames, 640x480, 6 levels, $MODE (tools/seq_profile.sh)\n\n")
-    o.write(open("$OUT/run.log").read().strip().splitlines()[-1] + "\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    o.write([l for l in open("$OUT/run.log").read().splitlines() if "frames/s" in l][-1] + "\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:14]:
         o.write(f"| {r['Name'][:90]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |\n")
 print(open("$OUT/kernel_stats.md").read()[:1500])
