@@ -54,8 +54,15 @@ enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1, VORS_CANDI
  *     Per-point values agree to a few ulp. Parity statement (measured, 640x480 6 levels, bench.py `parity`): the fraction of pairs
  *     beyond 1e-4 rad / 1e-4 m of the oracle equals that of EXACT and of the oracle against its own f64-accumulation build (~0.05 %:
  *     pairs whose LM path forks on the ORDER of the f32 sums); it is NOT zero for any arithmetic, and pyramids of < 5 levels on large
- *     images exceed 1e-4 from summation order alone (DESIGN.md §4 "short pyramids"). About 1.5-2x as fast as EXACT. */
-enum { VORS_ARITH_EXACT = 0, VORS_ARITH_FUSED = 1 };
+ *     images exceed 1e-4 from summation order alone (DESIGN.md §4 "short pyramids"). About 1.5-2x as fast as EXACT.
+ * 2 = REFERENCE: EXACT's per-point arithmetic AND the reference's summation: candidates in extract_z's column-major order
+ *     (inverse_compositional.rs:260-279; the lists are sorted once per keyframe), `energy_sum += r * r`, `gradient += jac * r`,
+ *     `hessian += hes` (lm_optimizer.rs:72-84,94-100) as sequential f32 multiply-then-add chains, one lane per sum, the optical-flow
+ *     sum of the keyframe test likewise, and sinf / cosf of se3::exp as glibc computes them. The device then takes the oracle's LM path
+ *     decision for decision: iteration counts equal at every level and poses BIT-IDENTICAL to the oracle's (tests/test_gpu_reference.py,
+ *     bench.py `parity_reference`) — the deterministic parity anchor that EXACT and FUSED are gated against. 2-3x slower than EXACT
+ *     (the chain of dependent additions); every candidate mode, Huber, the trackers and the operator level support it. */
+enum { VORS_ARITH_EXACT = 0, VORS_ARITH_FUSED = 1, VORS_ARITH_REFERENCE = 2 };
 
 /* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
 enum { VORS_TRACK_OK = 0, VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT = 1 };
@@ -97,7 +104,9 @@ int vors_device_count(void);
 vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes);
 /* ABI version of this header: bump on any signature change. */
 int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level
-                              * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version */
+                              * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version, vors_pipeline_*, vors_device_info,
+                              *    vors_tracker_track_checked
+                              * 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces
@@ -317,6 +326,8 @@ typedef struct vors_obs {
     const float* _z_candidates; /* Obs::_z_candidates: inverse depths, f32[n] */
     const float* jacobians;     /* Obs::jacobians: f32[6n] */
     float huber_delta;          /* extension, <= 0 = reference */
+    int32_t arithmetic;         /* VORS_ARITH_EXACT (sums in the device's tree order) or VORS_ARITH_REFERENCE: sequential f32 sums in the
+                                 * order of `coordinates` — the reference's eval on this Obs, bit for bit (lm_optimizer.rs:68-107) */
 } vors_obs;
 
 vors_status vors_lm_eval(const vors_obs* obs, const float model7[7], float* energy, int32_t* n_inside, float g[6],
@@ -335,6 +346,9 @@ vors_status vors_lm_solve(const vors_obs* obs, const float model7[7], float out_
  * ---------------------------------------------------------------------------------------------------------- */
 void vors_se3_exp(const float xi[6], float out_iso7[7]);
 void vors_se3_log(const float iso7[7], float out_xi[6]);
+/* sinf / cosf as se3::exp evaluates them here, host and device alike (csrc/lie.h ref_sinf / ref_cosf: glibc's algorithm restated; equal to
+ * the platform's sinf / cosf for every f32 in [0, 4), which tests/test_oracle_kat.py checks exhaustively). Outputs nullable. */
+void vors_ref_sincos(const float* x, int n, float* sin_out, float* cos_out);
 void vors_so3_exp(const float w[3], float out_q4[4]);
 void vors_so3_log(const float q4[4], float out_w[3]);
 void vors_iso_mul(const float a7[7], const float b7[7], float out7[7]);

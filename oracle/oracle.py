@@ -404,6 +404,14 @@ def dso_mask(img, nb_target=2000, seed=0x5EEDD50):
     return mask, list(bs[:n])
 
 
+def libm_sincos(x):
+    """std::sin / std::cos on float32, as the oracle's se3::exp calls them (the platform libm) -> (sin, cos)."""
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().vo_libm_sincos(_f32(x), x.size, _f32(s), _f32(c))
+    return s, c
+
+
 def prune_with_thresh(thresh, a, b, c, d):
     out = np.zeros(4, np.uint8)
     lib().vo_prune_with_thresh(thresh, a, b, c, d, _u8(out))

@@ -333,6 +333,14 @@ void vo_prune_with_thresh(int thresh, int a, int b, int c, int d, uint8_t out[4]
     candidates::prune_with_thresh((uint16_t)thresh, (uint16_t)a, (uint16_t)b, (uint16_t)c, (uint16_t)d, r);
     for (int k = 0; k < 4; ++k) out[k] = r[k];
 }
+// std::sin / std::cos on f32 exactly as se3::exp / so3::exp call them (= the platform libm's sinf / cosf, which is what Rust's f32::sin /
+// f32::cos call): the yardstick for the product's restatement of that algorithm (csrc/lie.h ref_sinf / ref_cosf).
+void vo_libm_sincos(const float* x, int n, float* s, float* c) {
+    for (int i = 0; i < n; ++i) {
+        s[i] = std::sin(x[i]);
+        c[i] = std::cos(x[i]);
+    }
+}
 void vo_se3_exp(const float xi[6], float out7[7]) { Vec6 v; std::memcpy(v.v, xi, 24); pose_to7(se3::exp(v), out7); }
 void vo_se3_log(const float in7[7], float xi[6]) { const Vec6 v = se3::log(pose_from7(in7)); std::memcpy(xi, v.v, 24); }
 void vo_se3_hat(const float xi[6], float out16[16]) { Vec6 v; std::memcpy(v.v, xi, 24); const Mat4 m = se3::hat(v); std::memcpy(out16, m.m, 64); }

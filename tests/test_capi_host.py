@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(V.EXPORTED_SYMBOLS)
-    assert lib.vors_abi_version() == 3   # 3: vors_trackers_*, vors_synth_render_frames
+    assert lib.vors_abi_version() == 4   # 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos
 
 
 def test_struct_layouts_match_header():
@@ -129,3 +129,28 @@ def test_multi_gpu_entry_fails_loudly_without_gpu():
         V.MultiGpu(V.Config(nb_levels=3), 4, 32, 32)
     with pytest.raises(V.VorsError, match="no HIP device"):
         V.Batch(V.Config(nb_levels=3), 4, 32, 32, device=0)
+
+
+def test_ref_sincos_equals_the_platform_libm_for_every_f32_in_its_range():
+    """se3::exp's sinf / cosf (se3.rs:82-87; Rust's f32::sin / cos = the platform libm = glibc's algorithm) are restated in csrc/lie.h so
+    that host and DEVICE evaluate them identically (ocml's sinf differs from glibc's in ~1 % of the arguments, and glibc's is not the
+    correctly rounded sine either). The restatement must equal the oracle's std::sin / std::cos for EVERY float32 in [0, 4): the whole
+    range is enumerated here (2^30 + ... values; ~1 s per 2^24)."""
+    lo = np.array([0.0], np.float32).view(np.uint32)[0]
+    hi = np.array([4.0], np.float32).view(np.uint32)[0]
+    step = 1 << 24
+    bad = 0
+    for start in range(int(lo), int(hi), step):
+        bits = np.arange(start, min(start + step, int(hi)), dtype=np.uint32)
+        x = bits.view(np.float32)
+        if x[-1] < 2.0 ** -14:   # tiny arguments: sin x = x, cos x = 1 in both (se3::exp never gets below 5e-3); sample them
+            x = x[:: 4096]
+        s1, c1 = V.ref_sincos(x)
+        s2, c2 = O.libm_sincos(x)
+        bad += int((s1.view(np.uint32) != s2.view(np.uint32)).sum()) + int((c1.view(np.uint32) != c2.view(np.uint32)).sum())
+    assert bad == 0
+    # beyond the restated range the platform function is used: still equal
+    x = np.linspace(4.0, 50.0, 10001).astype(np.float32)
+    s1, c1 = V.ref_sincos(x)
+    s2, c2 = O.libm_sincos(x)
+    assert (s1 == s2).all() and (c1 == c2).all()

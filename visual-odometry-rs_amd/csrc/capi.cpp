@@ -62,7 +62,7 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
         return fail(VORS_ERR_INVALID_ARGUMENT, "candidates_diff_threshold must fit u16");
     std::memset(g, 0, sizeof(*g));
     g->L = cfg->nb_levels;
-    if (cfg->arithmetic != VORS_ARITH_EXACT && cfg->arithmetic != VORS_ARITH_FUSED)
+    if (cfg->arithmetic != VORS_ARITH_EXACT && cfg->arithmetic != VORS_ARITH_FUSED && cfg->arithmetic != VORS_ARITH_REFERENCE)
         return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
     g->mode = cfg->candidates_mode;
     g->arith = cfg->arithmetic;
@@ -144,6 +144,7 @@ struct vors_batch {
     LmSplitWs split{};
     uint64_t bytes = 0;
     int lm_block = 256;  // threads per frame pair in the LM kernel (256 / 512 / 1024)
+    bool owns_sort_tmp = false;  // rec.sort_tmp is an allocation of its own (DSO mode, REFERENCE arithmetic), not the staging grid
     // generic-mask (DSO) mode workspaces
     DsoWs dso{};
     PixelPlanes pp{};
@@ -173,6 +174,7 @@ static void batch_free(vors_batch* b) {
     if (b->rec.IZ) (void)hipFree(b->rec.IZ);
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
+    if (b->owns_sort_tmp && b->rec.sort_tmp) (void)hipFree(b->rec.sort_tmp);
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state, b->dso.pick_list,
                      b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used, b->rec.S, b->rec.stage, b->rec.region_cnt,
                      b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
@@ -235,7 +237,7 @@ int vors_device_count(void) {
     }
     return n;
 }
-int vors_abi_version(void) { return 3; }
+int vors_abi_version(void) { return 4; }
 
 vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes) {
     vors_status st = require_device();
@@ -317,6 +319,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
             keyframe_region_geometry(g, &b->rec.kf_r, &b->rec.n_regions);
             if (e == hipSuccess) e = dmalloc(&b->rec.stage, slots, &b->bytes);
             if (e == hipSuccess) e = dmalloc(&b->rec.region_cnt, np * VORS_MAX_LEVELS * (size_t)b->rec.n_regions, &b->bytes);
+            b->rec.sort_tmp = b->rec.stage;  // (free once the regions have been compacted)
+        } else if (g.arith == VORS_ARITH_REFERENCE) {
+            if (e == hipSuccess) e = dmalloc(&b->rec.sort_tmp, slots, &b->bytes);
+            b->owns_sort_tmp = true;
         }
     }
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DSO) {
@@ -490,6 +496,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     } else {
         launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
     }
+    if (b->g.arith == VORS_ARITH_REFERENCE) launch_sort_colmajor(b->g, b->rec, n_pairs, s);  // extract_z's order (inverse_compositional.rs:260-279)
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -509,7 +516,10 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
     launch_pyramid(b->g, cur, n_pairs, s);
     STAGE_END(b, 2, s);
     STAGE_BEGIN(b, 3, s);
-    launch_lm_track(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, b->lm_block, b->split, s);
+    if (b->g.arith == VORS_ARITH_REFERENCE)
+        launch_lm_track_reference(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, s);
+    else
+        launch_lm_track(b->g, cur, Pyramid{b->kf_level0, b->kf_upper}, b->kf_depth, b->rec, d_prev_poses7, d_kf_poses7, d_out_poses7, d_out_status, d_out_stats, n_pairs, b->lm_block, b->split, s);
     STAGE_END(b, 3, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -649,7 +659,8 @@ vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const floa
     if (pair < 0 || pair >= std::min(b->prepared_pairs, b->current_pairs) || level < 0 || level >= b->g.L)
         return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range (pair must be < the n_pairs of the last prepare_keyframes AND track_current)");
     if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
-    if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED) return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
+    if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED && arithmetic != VORS_ARITH_REFERENCE)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
     DeviceGuard guard(b->device);
     DevBuf d_model, d_out;
     HIP_TRY(d_model.alloc(7 * sizeof(float)));
@@ -657,7 +668,9 @@ vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const floa
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d_model.p, model7, 7 * sizeof(float), hipMemcpyHostToDevice));
     const Pyramid cur{b->cur_level0, b->cur_upper}, kf{b->kf_level0, b->kf_upper};
-    if (arithmetic == VORS_ARITH_FUSED)
+    if (arithmetic == VORS_ARITH_REFERENCE)  // sequential sums in the order of the handle's lists (column-major iff the handle itself is REFERENCE)
+        launch_lm_eval_level_reference(b->g, cur, kf, b->kf_depth, b->rec, pair, level, d_model.as<float>(), d_out.as<float>(), nullptr);
+    else if (arithmetic == VORS_ARITH_FUSED)
         launch_lm_eval_level_fused(b->g, cur, kf, b->kf_depth, b->rec, pair, level, d_model.as<float>(), d_out.as<float>(), nullptr);
     else
         launch_lm_eval_level_exact(b->g, cur, kf, b->kf_depth, b->rec, pair, level, d_model.as<float>(), d_out.as<float>(), nullptr);
@@ -1214,6 +1227,7 @@ static vors_status trackers_promote(vors_trackers* t, const uint8_t* d_gray, con
     } else {
         launch_keyframe(gm, Pyramid{d_gray, b->cur_upper}, d_depth, b->rec, n, s);
     }
+    if (b->g.arith == VORS_ARITH_REFERENCE) launch_sort_colmajor(gm, b->rec, n, s);
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -1273,6 +1287,8 @@ struct ObsDev {
 static vors_status upload_obs(const vors_obs* o, const float model7[7], ObsDev& d, bool want_res, hipStream_t s) {
     if (!o || !model7) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (o->rows < 2 || o->cols < 2 || o->n < 0) return fail(VORS_ERR_INVALID_ARGUMENT, "bad observation shape");
+    if (o->arithmetic != VORS_ARITH_EXACT && o->arithmetic != VORS_ARITH_REFERENCE)
+        return fail(VORS_ERR_INVALID_ARGUMENT, "vors_obs.arithmetic must be VORS_ARITH_EXACT or VORS_ARITH_REFERENCE");
     if (!o->template_ || !o->image || (o->n > 0 && (!o->coordinates || !o->_z_candidates || !o->jacobians)))
         return fail(VORS_ERR_INVALID_ARGUMENT, "NULL observation array");
     vors_status st = require_device();
@@ -1317,8 +1333,12 @@ vors_status vors_lm_eval(const vors_obs* obs, const float model7[7], float* ener
     hipStream_t s = nullptr;
     vors_status st = upload_obs(obs, model7, d, residuals != nullptr, s);
     if (st != VORS_OK) return st;
-    launch_lm_eval_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
-                       d.out.as<float>(), residuals ? d.res.as<float>() : nullptr, s);
+    if (obs->arithmetic == VORS_ARITH_REFERENCE)
+        launch_lm_eval_obs_reference(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                                     d.out.as<float>(), residuals ? d.res.as<float>() : nullptr, s);
+    else
+        launch_lm_eval_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                           d.out.as<float>(), residuals ? d.res.as<float>() : nullptr, s);
     float out[44];
     HIP_TRY(hipMemcpyAsync(out, d.out.p, sizeof(out), hipMemcpyDeviceToHost, s));
     if (residuals && obs->n) HIP_TRY(hipMemcpyAsync(residuals, d.res.p, (size_t)obs->n * 4, hipMemcpyDeviceToHost, s));
@@ -1338,8 +1358,12 @@ vors_status vors_lm_solve(const vors_obs* obs, const float model7[7], float out_
     hipStream_t s = nullptr;
     vors_status st = upload_obs(obs, model7, d, false, s);
     if (st != VORS_OK) return st;
-    launch_lm_solve_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
-                        d.out.as<float>(), s);
+    if (obs->arithmetic == VORS_ARITH_REFERENCE)
+        launch_lm_solve_obs_reference(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                                      d.out.as<float>(), s);
+    else
+        launch_lm_solve_obs(d.k, obs->rows, obs->cols, d.img.as<uint8_t>(), obs->n, d.rec, obs->huber_delta, d.model.as<float>(),
+                            d.out.as<float>(), s);
     float out[11];
     HIP_TRY(hipMemcpyAsync(out, d.out.p, sizeof(out), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1366,6 +1390,12 @@ vors_status vors_lm_step(const float H[36], const float g[6], const float model7
 // Lie helpers (host arithmetic)
 // ---------------------------------------------------------------------------------------------------------------
 void vors_se3_exp(const float xi[6], float out_iso7[7]) { iso_store(se3_exp(xi), out_iso7); }
+void vors_ref_sincos(const float* x, int n, float* sin_out, float* cos_out) {
+    for (int i = 0; i < n; ++i) {
+        if (sin_out) sin_out[i] = ref_sinf(x[i]);
+        if (cos_out) cos_out[i] = ref_cosf(x[i]);
+    }
+}
 void vors_se3_log(const float iso7[7], float out_xi[6]) { se3_log(iso_load(iso7), out_xi); }
 void vors_so3_exp(const float w[3], float out_q4[4]) {
     const Quat q = so3_exp(w);

@@ -80,6 +80,8 @@ struct Records {
     int* region_cnt;    // coarse-to-fine mode: [pair][level][region] points per wavefront region
     int n_regions;      //   regions per level (= wavefronts of the keyframe kernel per pair)
     int kf_r;           //   roots per wavefront region
+    SlimRec* sort_tmp;  // REFERENCE arithmetic, sparse modes: scratch of the column-major sort (lm_reference.hip), laid out like S; the
+                        // coarse-to-fine mode lends its staging grid, which is free once the regions have been compacted
 };
 
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
@@ -177,6 +179,17 @@ void launch_lm_track_exact(const Geom& g, Pyramid cur, Pyramid kf, const uint16_
                            float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
 void launch_lm_track_fused(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7, const float* kf_poses7,
                            float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, int block, LmSplitWs split, hipStream_t s);
+// REFERENCE arithmetic (lm_reference.hip): the candidate lists of n_pairs pairs into extract_z's column-major order (no-op in dense mode;
+// honours Geom::sel_list), and the tracker with the reference's sequential sums.
+void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s);
+void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
+                               const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, hipStream_t s);
+void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
+                                    const float* model7, float* out29, hipStream_t s);
+void launch_lm_eval_obs_reference(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta, const float* model7,
+                                  float* out_energy_n_g_h, float* residuals, hipStream_t s);
+void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta, const float* model7,
+                                   float* out, hipStream_t s);
 // One evaluation of one level of one pair of a prepared batch at an explicit model, per arithmetic mode -> 29 sums.
 void launch_lm_eval_level_exact(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
                                 const float* model7, float* out29, hipStream_t s);

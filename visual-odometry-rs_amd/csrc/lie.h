@@ -86,6 +86,41 @@ VORS_HD Iso renormalize(Iso m) {
     return m;
 }
 
+// sinf / cosf as the reference computes them: Rust's f32::sin / cos call the platform libm, i.e. glibc's sinf / cosf (>= 2.28: the
+// ARM optimized-routines algorithm — argument widened to f64, |x| < pi/4: odd / even polynomial in f64; otherwise x - n pi/2 with
+// n = round(x 2/pi) and the polynomial selected by the quadrant — rounded ONCE to f32). That function is NOT the correctly rounded
+// sine (1 % of the arguments in [1e-3, 4] differ from RN(sin x) by one ulp), and the device's ocml sinf is a third function, so the
+// algorithm is restated here, host + device: bit-identical to glibc 2.35's sinf / cosf for EVERY f32 in [2^-12, 4) — with or
+// without FMA contraction of the f64 polynomial (checked exhaustively: tests/test_oracle_kat.py + oracle/sincos_check.c). se3::exp
+// only calls them with theta / 2 and theta, theta >= 0.01 (se3.rs:82-87); arguments >= 4 rad go to the platform function.
+VORS_HD float ref_sincos_poly(double x, int n) {
+    const double x2 = x * x;
+    if ((n & 1) == 0) {
+        const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+        const double x3 = x * x2, s1 = S2 + x2 * S3, x7 = x3 * x2, s = x + x3 * S1;
+        return (float)(s + x7 * s1);
+    }
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double x4 = x2 * x2, c2 = C3 + x2 * C4, c1 = C0 + x2 * C1, x6 = x4 * x2, c = c1 + x4 * C2;
+    return (float)(c + x6 * c2);
+}
+VORS_HD float ref_sincos(float y, int quadrant_shift) {  // 0: sin, 1: cos; 0 <= y < 4
+    double x = (double)y;
+    int n = 0;
+    if (!(y < 0x1.921fb6p-1f)) {  // pi/4
+        const double r = x * 0x1.45F306DC9C883p+23;  // x * 2/pi * 2^24
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * 0x1.921FB54442D18p0;
+    } else if (y < 0x1p-12f) {
+        return quadrant_shift ? 1.0f : y;
+    }
+    n += quadrant_shift;
+    const float v = ref_sincos_poly((n & 2) && !(n & 1) ? -x : x, n);
+    return ((n & 2) && (n & 1)) ? -v : v;
+}
+VORS_HD float ref_sinf(float y) { return (y >= 0.f && y < 4.0f) ? ref_sincos(y, 0) : sinf(y); }
+VORS_HD float ref_cosf(float y) { return (y >= 0.f && y < 4.0f) ? ref_sincos(y, 1) : cosf(y); }
+
 // reference: src/math/se3.rs:65-95 with so3::hat / hat_2 (src/math/so3.rs:27-51) expanded in place.
 VORS_HD Iso se3_exp(const float xi[6]) {
     const float vx = xi[0], vy = xi[1], vz = xi[2];
@@ -100,10 +135,10 @@ VORS_HD Iso se3_exp(const float xi[6]) {
     } else {
         const float theta = sqrtf(theta_2);
         const float half_theta = 0.5f * theta;
-        real_factor = cosf(half_theta);
-        imag_factor = sinf(half_theta) / theta;
-        c1 = (1.0f - cosf(theta)) / theta_2;
-        c2 = (theta - sinf(theta)) / (theta * theta_2);
+        real_factor = ref_cosf(half_theta);
+        imag_factor = ref_sinf(half_theta) / theta;
+        c1 = (1.0f - ref_cosf(theta)) / theta_2;
+        c2 = (theta - ref_sinf(theta)) / (theta * theta_2);
     }
     const float w11 = wx * wx, w12 = wx * wy, w13 = wx * wz, w22 = wy * wy, w23 = wy * wz, w33 = wz * wz;
     const float O[3][3] = {{0.0f, -wz, wy}, {wz, 0.0f, -wx}, {-wy, wx, 0.0f}};

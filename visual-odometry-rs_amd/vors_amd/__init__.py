@@ -26,7 +26,7 @@ MAX_LEVELS = 8
 ROW_MAJOR, COL_MAJOR = 0, 1
 CANDIDATES_COARSE_TO_FINE, CANDIDATES_DENSE, CANDIDATES_DSO = 0, 1, 2
 TRACK_OK, TRACK_OPTIMIZER_FAILED_POSE_KEPT = 0, 1
-ARITH_EXACT, ARITH_FUSED = 0, 1
+ARITH_EXACT, ARITH_FUSED, ARITH_REFERENCE = 0, 1, 2
 
 
 class VorsError(RuntimeError):
@@ -85,6 +85,7 @@ class vors_obs(C.Structure):
         ("_z_candidates", C.POINTER(C.c_float)),
         ("jacobians", C.POINTER(C.c_float)),
         ("huber_delta", C.c_float),
+        ("arithmetic", C.c_int32),
     ]
 
 
@@ -99,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "vors_batch_destroy",
     "vors_batch_get_keyframe_image", "vors_batch_get_current_image", "vors_batch_get_points", "vors_batch_eval_level",
     "vors_lm_eval", "vors_lm_step", "vors_lm_solve",
-    "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
+    "vors_ref_sincos", "vors_se3_exp", "vors_se3_log", "vors_so3_exp", "vors_so3_log", "vors_iso_mul", "vors_iso_inverse",
     "vors_synth_render_pairs",
     "vors_multi_create", "vors_multi_device_count", "vors_multi_shard", "vors_multi_track_pairs", "vors_multi_track_pairs_host",
     "vors_multi_destroy", "vors_multi_rccl_version",
@@ -182,6 +183,8 @@ def lib():
         _lib.vors_batch_get_points.argtypes = [vp, i, i, i, vp, vp, vp, vp, C.POINTER(i)]
         _lib.vors_batch_eval_level.argtypes = [vp, i, i, vp, i, vp]
         _lib.vors_lm_eval.argtypes = [C.POINTER(vors_obs), vp, C.POINTER(f), C.POINTER(C.c_int32), vp, vp, vp]
+        _lib.vors_ref_sincos.argtypes = [vp, i, vp, vp]
+        _lib.vors_ref_sincos.restype = None
         _lib.vors_lm_step.argtypes = [vp, vp, vp, f, vp, C.POINTER(i)]
         _lib.vors_lm_solve.argtypes = [C.POINTER(vors_obs), vp, vp, C.POINTER(C.c_int32), C.POINTER(f), C.POINTER(f), C.POINTER(i)]
         _lib.vors_synth_render_pairs.argtypes = [C.c_uint64, i, i, i, vp, d, i, vp, vp, vp, vp, vp, vp]
@@ -675,7 +678,7 @@ def synth_render_pairs(seed0, n_pairs, rows, cols, cam5, motion_scale=1.0, inval
 class Obs:
     """lm_optimizer.rs:43-58 (hessians are recomputed on the device, not passed)."""
 
-    def __init__(self, intrinsics5, template, image, coordinates, _z_candidates, jacobians, huber_delta=0.0):
+    def __init__(self, intrinsics5, template, image, coordinates, _z_candidates, jacobians, huber_delta=0.0, arithmetic=ARITH_EXACT):
         self.intrinsics = np.ascontiguousarray(intrinsics5, np.float32)
         self.template = np.ascontiguousarray(template, np.uint8)
         self.image = np.ascontiguousarray(image, np.uint8)
@@ -683,6 +686,7 @@ class Obs:
         self._z_candidates = np.ascontiguousarray(_z_candidates, np.float32)
         self.jacobians = np.ascontiguousarray(jacobians, np.float32).reshape(-1, 6)
         self.huber_delta = float(huber_delta)
+        self.arithmetic = int(arithmetic)  # ARITH_REFERENCE: sequential sums in the order of `coordinates`
 
     def to_c(self):
         k = self.intrinsics
@@ -690,7 +694,7 @@ class Obs:
         u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float)
         return vors_obs(k[0], k[1], k[2], k[3], k[4], rows, cols, self.template.ctypes.data_as(u8p),
                         self.image.ctypes.data_as(u8p), len(self._z_candidates), self.coordinates.ctypes.data_as(i32p),
-                        self._z_candidates.ctypes.data_as(f32p), self.jacobians.ctypes.data_as(f32p), self.huber_delta)
+                        self._z_candidates.ctypes.data_as(f32p), self.jacobians.ctypes.data_as(f32p), self.huber_delta, self.arithmetic)
 
 
 def lm_eval(obs, model7, want_residuals=False):
@@ -703,6 +707,14 @@ def lm_eval(obs, model7, want_residuals=False):
     o = obs.to_c()
     _check(lib().vors_lm_eval(C.byref(o), _ptr(model7), C.byref(e), C.byref(n), _ptr(g), _ptr(H), _ptr(res)))
     return (e.value, n.value, g, H, res) if want_residuals else (e.value, n.value, g, H)
+
+
+def ref_sincos(x):
+    """sinf / cosf as se3::exp evaluates them on host and device (lie.h ref_sinf / ref_cosf) -> (sin, cos) float32 arrays."""
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().vors_ref_sincos(_ptr(x), x.size, _ptr(s), _ptr(c))
+    return s, c
 
 
 def lm_step(H, g, model7, lm_coef):
