@@ -44,6 +44,10 @@ def parse():
     p.add_argument("--pairs", type=int, default=4096,
                    help="frame pairs per GPU per step (weak scaling; BASELINE config 4's batch size). The headline uses 4096; the "
                         "SURVEY §8d count (256 = one pair per CU) is measured as well and reported under `batch_256`")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: --pairs per GPU whatever N (the driver's default contract). strong: BASELINE configs[3] as written — a FIXED batch of "
+                        "--total-pairs pairs sharded over the N ranks (ceil(total / N) each, the last rank takes the remainder)")
+    p.add_argument("--total-pairs", type=int, default=4096, help="--scaling strong: the fixed batch (BASELINE config 4: 4096)")
     p.add_argument("--candidates", choices=["dense", "c2f", "dso"], default="dense",
                    help="dense = BASELINE configs[1] (extension); c2f = the reference's coarse-to-fine selection; "
                         "dso = DSO-style selection (config 3; piecewise-constant synthetic texture)")
@@ -51,9 +55,10 @@ def parse():
     p.add_argument("--cols", type=int, default=640)
     p.add_argument("--levels", type=int, default=6)
     p.add_argument("--huber", type=float, default=0.0)
-    p.add_argument("--arith", choices=["fused", "exact"], default="fused",
+    p.add_argument("--arith", choices=["fused", "exact", "reference"], default="fused",
                    help="per-point arithmetic (include/vors_hip.h VORS_ARITH_*): fused = equivalent shorter f32 forms (poses within the 1e-4 "
-                        "parity bar, gated by tests/test_gpu_fused.py); exact = the reference's evaluation order (parity anchor)")
+                        "parity bar, gated by tests/test_gpu_fused.py); exact = the reference's evaluation order per point; reference = exact + the "
+                        "reference's sequential summation order: bit-identical to the oracle (the deterministic parity anchor)")
     p.add_argument("--cpu-pairs", type=int, default=-1, help="pairs timed on the CPU oracle (-1 = auto, 0 = skip)")
     p.add_argument("--parity-pairs", type=int, default=-1,
                    help="pairs of each measured workload compared with the oracle after the timed region (-1 = auto: 1024 dense / 4096 sparse on a "
@@ -111,11 +116,11 @@ def lm_counters(args):
     return e
 
 
-LM_STAGE_KERNELS = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel")
+LM_STAGE_KERNELS = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel", "lm_ref_track_kernel")
 ONCE_PER_STEP_KERNELS = ("dense_idepth_level1", "keyframe_sparse_kernel", "dso_rounds_kernel")  # launched exactly once per bench step
 
 
-def live_counters(args):
+def live_counters(args, candidates=None):
     """HBM traffic and VALU counters of the LM stage of one step, MEASURED IN THIS RUN: three short rocprofv3 passes of this very command
     (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`; each its own process with --kernel-trace only, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), 2 steps each, after the timed region.
@@ -127,7 +132,7 @@ def live_counters(args):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return {}
-    child = [sys.executable, os.path.abspath(__file__), "--pairs", str(args.pairs), "--steps", "2", "--warmup", "1", "--candidates", args.candidates,
+    child = [sys.executable, os.path.abspath(__file__), "--pairs", str(args.pairs), "--steps", "2", "--warmup", "1", "--candidates", candidates or args.candidates,
              "--arith", args.arith, "--rows", str(args.rows), "--cols", str(args.cols), "--levels", str(args.levels), "--huber", str(args.huber),
              "--no-secondary", "--cpu-pairs", "0", "--parity-pairs", "0", "--no-pmc", "--no-sequences"]
     out, t0 = {}, time.perf_counter()
@@ -161,6 +166,10 @@ def live_counters(args):
     return out
 
 
+def arith_id(V, name):
+    return {"fused": V.ARITH_FUSED, "exact": V.ARITH_EXACT, "reference": V.ARITH_REFERENCE}[name]
+
+
 class Workload:
     def __init__(self, V, args, mode, device, seed0, pairs=None):
         self.V, self.args, self.mode = V, args, mode
@@ -170,7 +179,7 @@ class Workload:
         self.mode_id = {"dense": V.CANDIDATES_DENSE, "c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO}[mode]
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(self.intr[:2], self.intr[2:4], self.intr[4]),
                        candidates_mode=self.mode_id, huber_delta=args.huber,
-                       arithmetic=V.ARITH_FUSED if args.arith == "fused" else V.ARITH_EXACT)
+                       arithmetic=arith_id(V, args.arith))
         if mode == "dso":
             seed0 |= 1 << 63  # piecewise-constant texture: the DSO thresholds reject the smooth texture entirely
         self.cfg = cfg
@@ -235,13 +244,13 @@ def host_pairs(work, n):
     return (work.kg[:n].cpu().numpy(), work.kd[:n].cpu().numpy().view(np.uint16), work.cg[:n].cpu().numpy())
 
 
-def cpu_baseline(args, work, value):
+def cpu_baseline(args, work, value, n_override=None):
     """the oracle (C++ restatement of the reference, `kind: port`) on a bounded sample of the same pairs — a
     -march=native build made on THIS host (FMA contraction stays off: the arithmetic is the oracle's), one pinned thread like the
     single-threaded reference, 1 warm-up + median of 5 runs; plus an all-cores figure."""
     from oracle import oracle as O
-    dense = args.candidates == "dense"
-    n_cpu = args.cpu_pairs
+    dense = work.mode == "dense"
+    n_cpu = args.cpu_pairs if n_override is None else n_override
     if n_cpu < 0:
         n_cpu = 48 if dense else 1024      # ≈ 2 s (dense) / 2.5 s (sparse) per single-thread run at 640x480; x 6 runs + the all-cores leg
         scale = (args.rows * args.cols) / (480.0 * 640.0)
@@ -375,7 +384,7 @@ def sequences_bench(V, args, device, n_seq=64, n_frames=40):
                                                 [base * sign[s] * speed[s] * k for s in range(n_seq)], rows, cols, intr, device=device))
         mode_id = {"c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO, "dense": V.CANDIDATES_DENSE}[mode]
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode_id,
-                       arithmetic=V.ARITH_FUSED if args.arith == "fused" else V.ARITH_EXACT)
+                       arithmetic=arith_id(V, args.arith))
         tr = V.Trackers(cfg, n_seq, rows, cols)
         for _ in range(2):  # the first pass warms up; the second is timed
             tr.init(*frames[0])
@@ -420,16 +429,84 @@ def sequences_bench(V, args, device, n_seq=64, n_frames=40):
         err64 = np.abs(ref64["poses"] - ref["poses"]).max(axis=(1, 2))
         fps = n_seq * (n_frames - 1) / dt
         cpu_fps = (n_frames - 1) / t_cpu
+        # the same sequences in the REFERENCE arithmetic (the reference's summation order): every pose of every frame must equal the
+        # oracle tracker's BIT FOR BIT, keyframe decisions included
+        ref_mode = None
+        if args.arith != "reference":
+            import copy
+            rcfg = copy.copy(cfg)
+            rcfg.arithmetic = V.ARITH_REFERENCE
+            rt = V.Trackers(rcfg, n_seq, rows, cols)
+            rt.init(*frames[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rtraj = []
+            for k in range(1, n_frames):
+                rt.track(*frames[k])
+                rtraj.append(rt.current_frames()[0])
+            dtr = time.perf_counter() - t0
+            rtraj = np.stack(rtraj, axis=1)
+            same = (rtraj.view(np.uint32) == ref["poses"].view(np.uint32)).all(axis=(1, 2))
+            ref_mode = {"n_sequences_bit_identical_to_oracle_tracker": int(same.sum()),
+                        "max_pose_diff_vs_oracle_tracker": float(np.abs(rtraj - ref["poses"]).max()),
+                        "frames_per_s_incl_readback": round(n_seq * (n_frames - 1) / dtr, 1)}
+            del rt
         out[mode] = {"frames_per_s": round(fps, 1), "ms_per_lockstep_frame": round(dt / (n_frames - 1) * 1e3, 4), "sequences": n_seq,
                      "frames_per_sequence": n_frames - 1, "keyframe_switches": switches,
                      "keyframe_switches_oracle": int(ref["changed_keyframe"].sum()),
                      "cpu_oracle_tracker_frames_per_s_1core": round(cpu_fps, 1), "gpu_over_cpu_1core": round(fps / cpu_fps, 1),
                      "max_pose_diff_vs_oracle_tracker": float(err.max()), "median_pose_diff_vs_oracle_tracker": float(np.median(err)),
                      "n_sequences_beyond_tol": int((err > 1e-4).sum()),
-                     "n_sequences_beyond_tol_oracle_f32_vs_f64_accumulation": int((err64 > 1e-4).sum()), "sequences_compared": n_seq}
+                     "n_sequences_beyond_tol_oracle_f32_vs_f64_accumulation": int((err64 > 1e-4).sum()), "sequences_compared": n_seq,
+                     "reference_arithmetic": ref_mode}
         del tr, frames, gh, dh
     out["note"] = (f"{args.cols}x{args.rows}, {L} levels, {args.arith} arithmetic; frames resident in HBM; a lock-step frame = one vors_trackers_track call "
                    "for all 64 sequences; the trajectory error is the max over all frames of a sequence (errors accumulate along a sequence)")
+    return out
+
+
+def reference_parity(V, args, device, seed0, sizes):
+    """VORS_ARITH_REFERENCE (the reference's summation order on the device) over full-size samples of the three candidate modes against
+    the oracle: the expectation is EQUALITY OF BITS — every pose, every iteration count — so the block reports counts of identical
+    pairs, not a tolerance; plus the mode's own throughput."""
+    import copy
+    from oracle import oracle as O
+    out = {}
+    ncores = os.cpu_count() or 1
+    for mode in ("c2f", "dso", "dense"):
+        n = min(sizes[mode], args.pairs)
+        if n <= 0:
+            continue
+        a = copy.copy(args)
+        a.arith = "reference"
+        w = Workload(V, a, mode, device, seed0, pairs=n)
+        w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3 if mode != "dense" else 1
+        for _ in range(reps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        kg, kd, cg = host_pairs(w, n)
+        ref = O.track_pairs(O.make_config(args.levels, w.intr, candidates_mode=w.mode_id, huber_delta=args.huber), kg, kd, cg, n_threads=min(ncores, n))
+        poses = w.poses.cpu().numpy()
+        st = V.decode_stats(w.stats)
+        L = args.levels
+        same_pose = (poses.view(np.uint32) == ref["poses"].view(np.uint32)).all(axis=1)
+        same_model = (np.ascontiguousarray(st["lm_model"]).view(np.uint32) == ref["models"].view(np.uint32)).all(axis=1)
+        same_iter = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1)
+        same_flow = np.ascontiguousarray(st["optical_flow"]).view(np.uint32) == ref["flow"].view(np.uint32)
+        err = np.abs(poses - ref["poses"]).max(axis=1)
+        out[mode] = {"sample_pairs": int(n), "n_poses_bit_identical": int(same_pose.sum()), "n_lm_models_bit_identical": int(same_model.sum()),
+                     "n_iteration_counts_equal_at_every_level": int(same_iter.sum()), "n_optical_flow_bit_identical": int(same_flow.sum()),
+                     "branch_flip_rate_gpu_vs_oracle": float((~same_iter).mean()), "n_beyond_tol": int((err > 1e-4).sum()),
+                     "max_pose_diff_gpu_vs_oracle": float(err.max(initial=0.0)),
+                     "status_equal": bool((w.status.cpu().numpy() == ref["status"]).all()),
+                     "frame_pairs_per_s": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+        del w
+    out["note"] = ("arithmetic = reference: EXACT's per-point arithmetic + the reference's sequential f32 sums in extract_z's column-major order "
+                   "(lm_reference.hip); compared with the oracle bit for bit")
     return out
 
 
@@ -470,6 +547,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     import vors_amd as V
 
+    if args.scaling == "strong":  # BASELINE configs[3] as written: a fixed batch sharded over the ranks (equal blocks: the gather wants them equal)
+        args.pairs = -(-args.total_pairs // world)
     seed0 = 0x5EED0000 + rank * args.pairs
     main_w = Workload(V, args, args.candidates, device, seed0)
     packed = torch.zeros((args.pairs, 8), dtype=torch.float32, device=device) if world > 1 else None
@@ -490,7 +569,7 @@ def main():
     lm_ms = main_w.batch.kernel_times("lm")[-args.steps:]
     kf_ms = main_w.batch.kernel_times("keyframe")[-args.steps:]
     pyr_ms = main_w.batch.kernel_times("pyramid_keyframe")[-args.steps:] + main_w.batch.kernel_times("pyramid_current")[-args.steps:]
-    total_pairs = world * args.pairs * args.steps
+    total_pairs = (args.total_pairs if args.scaling == "strong" else world * args.pairs) * args.steps
     value = total_pairs / dt
 
     stats = V.decode_stats(main_w.stats)
@@ -564,7 +643,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -575,6 +654,7 @@ def main():
                           if dense and (args.rows, args.cols, args.levels) == (960, 1280, 7) and args.huber > 0 else
                           f"synthetic {args.cols}x{args.rows} gray u8 + depth u16, {args.levels}-level pyramid, {args.candidates} candidates")),
             "pairs_per_gpu": args.pairs,
+            "total_pairs": (args.total_pairs if args.scaling == "strong" else world * args.pairs),
             "candidates": {"dense": "dense (all-true level-0 mask, extension)", "c2f": "coarse_to_fine (reference selection)",
                            "dso": "DSO-style selection (dso.rs, examples/candidates_dso.rs parameters)"}[args.candidates],
             "huber_delta": args.huber,
@@ -599,35 +679,62 @@ def main():
         out["self_check"] = multi_gpu_self_check(args, main_w, packed, gathered, rank, world)
     if rank == 0 and world == 1:
         if not args.no_secondary:
-            # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload
-            if args.pairs != 256:
-                ws = Workload(V, args, args.candidates, device, seed0, pairs=256)
-                ws.batch.enable_kernel_timing(ring)
-                dts = timed_run(ws, args.steps, args.warmup, 1, None, None)
-                out["batch_256"] = {"value": round(256 * args.steps / dts, 2), "unit": "frame-pairs/s", "pairs_per_gpu": 256,
-                                    "ms_per_step": round(dts / args.steps * 1e3, 4),
-                                    "lm_kernel_ms": round(float(ws.batch.kernel_times("lm")[-args.steps:].mean()), 5)}
-                del ws
-            # ---- the other candidate mode (the reference's own selection when the headline is dense)
-            if args.candidates != "dso":
-                other = "c2f" if dense else "dense"
+            # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload, and BASELINE config 4's per-GPU share on 8 GPUs (512)
+            for nb in (256, 512):
+                if args.pairs != nb:
+                    ws = Workload(V, args, args.candidates, device, seed0, pairs=nb)
+                    ws.batch.enable_kernel_timing(ring)
+                    dts = timed_run(ws, args.steps, args.warmup, 1, None, None)
+                    out[f"batch_{nb}"] = {"value": round(nb * args.steps / dts, 2), "unit": "frame-pairs/s", "pairs_per_gpu": nb,
+                                          "ms_per_step": round(dts / args.steps * 1e3, 4),
+                                          "lm_kernel_ms": round(float(ws.batch.kernel_times("lm")[-args.steps:].mean()), 5),
+                                          "step_time_ratio_vs_headline_batch": round((dt / args.steps) / (dts / args.steps), 3)}
+                    del ws
+            # ---- the other candidate modes, each with its own stage times, roofline block (I/O-only = SURVEY's conservative sparse headline,
+            # whole job, LM stage; live PMC traffic), CPU baseline (1 pinned core on a sample of the same pairs) and full-batch parity:
+            # `secondary` = the reference's own selection (coarse-to-fine) when the headline is dense, `dso` = config 3's selector
+            for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
+                if other == args.candidates:
+                    continue
                 w2 = Workload(V, args, other, device, seed0)
                 w2.batch.enable_kernel_timing(ring)
                 dt2 = timed_run(w2, args.steps, args.warmup, 1, None, None)
                 st2 = V.decode_stats(w2.stats)
-                io2, lmb2, _, ev2, _ = byte_model(st2, args.levels, args.rows, args.cols, other == "dense")
-                out["secondary"] = {
-                    "candidates": "coarse_to_fine (reference selection)" if other == "c2f" else "dense",
-                    "value": round(args.pairs * args.steps / dt2, 2), "unit": "frame-pairs/s",
+                io2, lmb2, lmflat2, ev2, _ = byte_model(st2, args.levels, args.rows, args.cols, other == "dense")
+                lm2 = float(w2.batch.kernel_times("lm")[-args.steps:].mean())
+                kf2 = float(w2.batch.kernel_times("keyframe")[-args.steps:].mean())
+                py2 = float((w2.batch.kernel_times("pyramid_keyframe")[-args.steps:] + w2.batch.kernel_times("pyramid_current")[-args.steps:]).mean())
+                val2 = args.pairs * args.steps / dt2
+                cnt2 = live_counters(args, other) if not args.no_pmc else {}
+                tr2 = cnt2.get("traffic_bytes")
+                lm_bytes2 = lmb2 + 32 * args.pairs
+                out[key] = {
+                    "candidates": {"c2f": "coarse_to_fine (reference selection)", "dense": "dense", "dso": "DSO-style selection (config 3)"}[other],
+                    "value": round(val2, 2), "unit": "frame-pairs/s",
                     "ms_per_step": round(dt2 / args.steps * 1e3, 4),
-                    "lm_kernel_ms": round(float(w2.batch.kernel_times("lm")[-args.steps:].mean()), 5),
+                    "stages_ms": {"pyramids": round(py2, 5), "keyframe": round(kf2, 5), "lm": round(lm2, 5)},
+                    "lm_kernel_ms": round(lm2, 5),
                     "lm_evals_per_pair": round(ev2, 2),
-                    "whole_job_GBps": round((io2 + lmb2) * args.steps / dt2 / 1e9, 2),
-                    "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2),
+                    "roofline": {
+                        "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2), "io_only_frac": round(io2 * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
+                        "whole_job_GBps": round((io2 + lmb2) * args.steps / dt2 / 1e9, 2),
+                        "whole_job_frac": round((io2 + lmb2) * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
+                        "lm_stage_achieved": round(lm_bytes2 / (lm2 * 1e-3) / 1e9, 2), "lm_stage_frac": round(lm_bytes2 / (lm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        "lm_stage_algorithmic_bytes": lm_bytes2, "traffic": tr2, "traffic_source": cnt2.get("source"),
+                        "traffic_over_algorithmic": (round(tr2 / lm_bytes2, 3) if tr2 else None),
+                        "note": "sparse modes: SURVEY §8(d) takes the I/O-only fraction as the conservative headline (the candidate lists are cache-sized)",
+                    },
                 }
+                if args.cpu_pairs != 0:
+                    out[key]["cpu_baseline"] = cpu_baseline(args, w2, val2, n_override=(48 if other == "dense" else 256) if args.cpu_pairs < 0 else args.cpu_pairs)
                 n_par = parity_sample_sizes(args)[other]
                 if n_par > 0:
-                    parity_secondary = parity_block(args, w2, n_par)
+                    pb = parity_block(args, w2, n_par)
+                    if key == "secondary":
+                        parity_secondary = pb
+                    else:
+                        out["parity_dso"] = pb
                 del w2
             # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
             # own batch of `pairs` pairs; the GPU overlaps the tail of one step — dependent straggler rounds, last workgroups of per-pair kernels — with the
@@ -657,6 +764,10 @@ def main():
             del pipe, w3
         if not args.no_sequences and not args.no_secondary:
             out["sequences_64"] = sequences_bench(V, args, device)
+        if not args.no_secondary and args.parity_pairs != 0 and args.arith != "reference":
+            sizes = parity_sample_sizes(args)
+            sizes["dense"] = min(sizes["dense"], 512)   # (the dense REFERENCE mode walks 409,500 points per evaluation sequentially)
+            out["parity_reference"] = reference_parity(V, args, device, seed0, sizes)
         if args.cpu_pairs != 0:
             out["cpu_baseline"] = cpu_baseline(args, main_w, value)
         n_par = parity_sample_sizes(args)[args.candidates]

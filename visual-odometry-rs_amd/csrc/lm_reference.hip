@@ -65,12 +65,13 @@ struct RefPt {
 struct RefSlimSrc {  // sparse modes: the sorted 12-byte lists
     const SlimRec* S;
     Intr k;
+    FastDiv fu, fv;  // the focal lengths as verified fast divisors (lie.h div_uniform: bit-identical to the IEEE quotient, or `ok` = 0)
     __device__ __forceinline__ void get(int i, RefPt& p) const {
         const SlimRec r = S[(unsigned)i];
         const float x = (float)(r.xy & 0xffffu), y = (float)(r.xy >> 16);
-        p.P = back_project(k, x, y, 1.0f / r.iz);
+        p.P = back_project_rt(IntrFast{k, fu, fv}, x, y, 1.0f / r.iz);
         p.tmpl = (float)(r.tg & 0xffu);
-        warp_jacobian_at((float)slim_gx(r.tg), (float)slim_gy(r.tg), x, y, r.iz, k, p.J);
+        warp_jacobian_at_rt((float)slim_gx(r.tg), (float)slim_gy(r.tg), x, y, r.iz, IntrFast{k, fu, fv}, p.J);
         p.valid = true;
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* iz, bool* valid) const {
@@ -343,7 +344,7 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
                         pair, lvl, lg.rows, lg.cols, lg.k};
         f(src, lg.rows * lg.cols);
     } else {
-        RefSlimSrc src{rec.S + (size_t)pair * g.slots_total + lg.slot_off, lg.k};
+        RefSlimSrc src{rec.S + (size_t)pair * g.slots_total + lg.slot_off, lg.k, lg.fu, lg.fv};
         f(src, __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]));
     }
 }
@@ -563,11 +564,12 @@ void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* im
 // candidate per pixel), so the rank of a candidate is the number of set bits below its key in a bitmap of the level: segments of 2^18
 // keys in LDS, per-thread word totals + a block scan. One workgroup per (level, pair); out of place into `tmp`, then copied back.
 // ------------------------------------------------------------------------------------------------------------
-#define SORT_WORDS 8192  // 262,144 keys per segment
-#define SORT_BLOCK 256
+#define SORT_WORDS 4096  // 131,072 keys per segment: 16 KB of bits + 16 KB of word prefixes
+#define SORT_BLOCK 512
+#define SORT_U 8          // independent loads in flight per thread (a pass is a chain of global round trips otherwise)
 __global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Records rec) {
     __shared__ uint32_t bits[SORT_WORDS];
-    __shared__ int pre[SORT_BLOCK];
+    __shared__ int wpre[SORT_WORDS];  // set bits in the words before this one (within the segment)
     __shared__ int wsum[SORT_BLOCK / 64];
     __shared__ int s_base;
     const int pair = select_pair(g, blockIdx.y);
@@ -580,21 +582,31 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Recor
     const size_t lvl0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
     SlimRec* S = rec.S + lvl0;
     SlimRec* T = rec.sort_tmp + lvl0;
-    constexpr int WPT = SORT_WORDS / SORT_BLOCK;  // words per thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
     for (unsigned seg0 = 0; seg0 < nkeys; seg0 += SORT_WORDS * 32u) {
-        for (int w = threadIdx.x; w < SORT_WORDS; w += SORT_BLOCK) bits[w] = 0u;
+        const unsigned seg_keys = min(nkeys - seg0, SORT_WORDS * 32u);
+        const int words = (int)((seg_keys + 31u) >> 5);
+        const int wpt = (words + SORT_BLOCK - 1) / SORT_BLOCK;  // consecutive words per thread
+        for (int w = threadIdx.x; w < words; w += SORT_BLOCK) bits[w] = 0u;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const uint32_t xy = S[i].xy;
-            const unsigned key = (xy & 0xffffu) * (unsigned)rows + (xy >> 16);
-            const unsigned rel = key - seg0;
-            if (rel < SORT_WORDS * 32u) atomicOr(&bits[rel >> 5], 1u << (rel & 31u));
+        for (int i0 = threadIdx.x; i0 < n; i0 += SORT_BLOCK * SORT_U) {
+            uint32_t xy[SORT_U];
+#pragma unroll
+            for (int u = 0; u < SORT_U; ++u) {
+                const int i = i0 + u * SORT_BLOCK;
+                xy[u] = i < n ? S[i].xy : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < SORT_U; ++u) {
+                const unsigned rel = (xy[u] & 0xffffu) * (unsigned)rows + (xy[u] >> 16) - seg0;
+                if (xy[u] != 0xffffffffu && rel < seg_keys) atomicOr(&bits[rel >> 5], 1u << (rel & 31u));
+            }
         }
         __syncthreads();
+        const int w0 = threadIdx.x * wpt, w1 = min(words, w0 + wpt);
         int tot = 0;
-        for (int w = 0; w < WPT; ++w) tot += __popc(bits[threadIdx.x * WPT + w]);
+        for (int w = w0; w < w1; ++w) tot += __popc(bits[w]);
         int incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -603,30 +615,50 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Recor
         }
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int excl = incl - tot;
-        for (int w = 0; w < wave; ++w) excl += wsum[w];
-        pre[threadIdx.x] = excl;
+        int run = incl - tot;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
         const int base = s_base;
+        for (int w = w0; w < w1; ++w) {
+            wpre[w] = run;
+            run += __popc(bits[w]);
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const SlimRec r = S[i];
-            const unsigned key = (r.xy & 0xffffu) * (unsigned)rows + (r.xy >> 16);
-            const unsigned rel = key - seg0;
-            if (rel < SORT_WORDS * 32u) {
-                const unsigned w = rel >> 5, owner = w / WPT;
-                int rank = base + pre[owner];
-                for (unsigned j = owner * WPT; j < w; ++j) rank += __popc(bits[j]);
-                rank += __popc(bits[w] & ((1u << (rel & 31u)) - 1u));
-                if (rank < n) T[rank] = r;
+        for (int i0 = threadIdx.x; i0 < n; i0 += SORT_BLOCK * (SORT_U / 2)) {
+            SlimRec r[SORT_U / 2];
+#pragma unroll
+            for (int u = 0; u < SORT_U / 2; ++u) {
+                const int i = i0 + u * SORT_BLOCK;
+                r[u] = i < n ? S[i] : SlimRec{0xffffffffu, 0.f, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < SORT_U / 2; ++u) {
+                const unsigned rel = (r[u].xy & 0xffffu) * (unsigned)rows + (r[u].xy >> 16) - seg0;
+                if (r[u].xy != 0xffffffffu && rel < seg_keys) {
+                    const unsigned w = rel >> 5;
+                    const int rank = base + wpre[w] + __popc(bits[w] & ((1u << (rel & 31u)) - 1u));
+                    if (rank < n) T[rank] = r[u];
+                }
             }
         }
         __syncthreads();
-        if (threadIdx.x == SORT_BLOCK - 1) s_base = base + excl + tot;
+        if (threadIdx.x == SORT_BLOCK - 1) s_base = base + run;  // (the last thread's running count = the segment's total)
         __syncthreads();
     }
     __threadfence();
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += SORT_BLOCK) S[i] = T[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += SORT_BLOCK * (SORT_U / 2)) {
+        SlimRec r[SORT_U / 2];
+#pragma unroll
+        for (int u = 0; u < SORT_U / 2; ++u) {
+            const int i = i0 + u * SORT_BLOCK;
+            if (i < n) r[u] = T[i];
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U / 2; ++u) {
+            const int i = i0 + u * SORT_BLOCK;
+            if (i < n) S[i] = r[u];
+        }
+    }
 }
 void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s) {
     if (g.mode == VORS_CANDIDATES_DENSE || !rec.sort_tmp) return;
