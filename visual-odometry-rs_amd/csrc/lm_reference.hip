@@ -644,7 +644,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Recor
         if (threadIdx.x == SORT_BLOCK - 1) s_base = base + run;  // (the last thread's running count = the segment's total)
         __syncthreads();
     }
-    __threadfence();
+    // (workgroup scope is all this needs — T was written by this workgroup and is read back by it, through the CU's own L1 / the XCD's
+    // L2; an agent-scope __threadfence() here writes the whole L2 back once per workgroup: 6 ms per 4096 pairs)
     __syncthreads();
     for (int i0 = threadIdx.x; i0 < n; i0 += SORT_BLOCK * (SORT_U / 2)) {
         SlimRec r[SORT_U / 2];
