@@ -114,30 +114,88 @@ def test_trackers_argument_checks():
         V.Trackers(cfg, 2, rows, cols, device=torch.cuda.device_count())
 
 
-@pytest.mark.parametrize("arith", [V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
-def test_config3_shape_640x480_dso_sequence_of_60_frames_vs_oracle(arith):
-    """BASELINE configs[2]'s real shape: a 640x480, 6-level SEQUENCE with DSO candidate selection (every keyframe switch re-runs the
-    selector on the frame that was current, inverse_compositional.rs:224-239), 60 tracked frames, through the single-sequence C ABI
-    tracker, against the oracle Tracker frame by frame. (fr1/desk itself is not available offline: synthetic frames of the same format.)
-    The tolerance is per frame on the ACCUMULATED pose: a sequence is a chain, an alignment that lands 1e-5 away moves every later pose."""
-    rows, cols, L, n = 480, 640, 6, 61
+def _dso_sequences(n_seq, n_frames, rows, cols, intr, seed0):
+    """n_seq DSO-textured sequences with their own seeds, speeds and directions -> device frames [F][n_seq, rows, cols] + host copies."""
+    import torch
+    base = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
+    rng = np.random.default_rng(seed0)
+    speed = 0.5 + 1.0 * rng.random(n_seq)
+    sign = rng.choice([-1.0, 1.0], size=(n_seq, 6))
+    frames = []
+    for k in range(n_frames):
+        frames.append(V.synth_render_frames([BLOCKY | (seed0 + s) for s in range(n_seq)], [k] * n_seq,
+                                            [base * sign[s] * speed[s] * k for s in range(n_seq)], rows, cols, intr))
+    torch.cuda.synchronize()
+    gh = np.stack([g.cpu().numpy() for g, _ in frames])
+    dh = np.stack([d.cpu().numpy().view(np.uint16) for _, d in frames])
+    return frames, gh, dh
+
+
+def _run_trackers(cfg, frames, n_seq, rows, cols):
+    many = V.Trackers(cfg, n_seq, rows, cols)
+    many.init(*frames[0])
+    traj, stat, sw = [], [], []
+    for k in range(1, len(frames)):
+        many.track(*frames[k])
+        poses, status, _ = many.current_frames()
+        traj.append(poses)
+        stat.append(status)
+        sw.append(many.stats()["change_keyframe"].copy())
+    return np.stack(traj, axis=1), np.stack(stat, axis=1), np.stack(sw, axis=1)
+
+
+def test_config3_shape_640x480_dso_sequences_16_seeds_of_60_frames_vs_oracle():
+    """BASELINE configs[2]'s real shape — 640x480, 6 levels, SEQUENCES with DSO candidate selection (every keyframe switch re-runs the
+    selector on the frame that was current, inverse_compositional.rs:224-239) — over SIXTEEN seeds x 60 tracked frames instead of the one
+    seed round 3 asserted on (a seed-selected pass). A tracked pose is a chain product, so one alignment that lands 1e-3 away
+    moves every later pose of its sequence.
+      REFERENCE arithmetic: every pose of every frame of every sequence equals the oracle tracker's BIT FOR BIT (and so do the keyframe
+      decisions and statuses) — asserted.
+      EXACT / FUSED: the number of sequences that leave the 1e-4 band anywhere along their 60 frames is REPORTED next to the oracle's own
+      f32-vs-f64-accumulation count and gated against it (the LM path forks on the order of the sums); no sequence may
+      drift further than 5e-3."""
+    rows, cols, L, n_seq, n = 480, 640, 6, 16, 61
     intr = O.INTRINSICS_FR1
-    step = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
-    g, d = V.synth_render_frames([BLOCKY | 31337] * n, list(range(n)), [step * k for k in range(n)], rows, cols, intr)
-    gh, dh = g.cpu().numpy(), d.cpu().numpy().view(np.uint16)
-    cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=V.CANDIDATES_DSO, arithmetic=arith)
-    vt = cfg.init(0.0, dh[0], 0.0, gh[0])
-    ot = O.Tracker(O.make_config(L, intr, candidates_mode=V.CANDIDATES_DSO), 0.0, dh[0], 0.0, gh[0], keep_debug=False)
-    switches, worst = 0, 0.0
-    for k in range(1, n):
-        assert ot.track(float(k), dh[k], float(k), gh[k]) == vt.track(float(k), dh[k], float(k), gh[k])
-        e = float(np.abs(ot.current_frame()[1] - vt.current_frame()[1]).max())
-        worst = max(worst, e)
-        assert e < POSE_TOL, f"frame {k}: {e}"
-        assert ot.last()["changed_keyframe"] == bool(vt.last_stats()["change_keyframe"]), f"frame {k}"
-        switches += int(ot.last()["changed_keyframe"])
-    assert switches >= 2
-    print(f"60 frames, {switches} keyframe switches, max accumulated pose difference {worst:.2e}")
+    frames, gh, dh = _dso_sequences(n_seq, n, rows, cols, intr, 31337)
+    ocfg = O.make_config(L, intr, candidates_mode=V.CANDIDATES_DSO)
+    ref = O.track_sequences(ocfg, gh, dh, n_threads=n_seq)
+    ref64 = O.track_sequences(ocfg, gh, dh, n_threads=n_seq, variant="acc64")
+    floor = int((np.abs(ref64["poses"] - ref["poses"]).max(axis=(1, 2)) > POSE_TOL).sum())
+    assert ref["changed_keyframe"].sum() >= n_seq
+    for arith, name in ((V.ARITH_REFERENCE, "reference"), (V.ARITH_EXACT, "exact"), (V.ARITH_FUSED, "fused")):
+        cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=V.CANDIDATES_DSO, arithmetic=arith)
+        traj, stat, sw = _run_trackers(cfg, frames, n_seq, rows, cols)
+        assert (stat == ref["status"]).all()
+        err = np.abs(traj - ref["poses"]).max(axis=(1, 2))
+        if arith == V.ARITH_REFERENCE:
+            assert (traj.view(np.uint32) == ref["poses"].view(np.uint32)).all(), f"REFERENCE: max difference {err.max():.3e}"
+            assert (sw == ref["changed_keyframe"]).all()
+        else:
+            n_out = int((err > POSE_TOL).sum())
+            print(f"{name}: {n_out} of {n_seq} sequences leave the 1e-4 band within 60 frames (oracle f32 vs f64 accumulation: {floor}); max {err.max():.2e}")
+            assert n_out <= floor + 3 and err.max() < 5e-3
+
+
+def test_config3_at_full_length_600_frame_dso_sequences_reference_arithmetic_bit_identical():
+    """configs[2] at the LENGTH of fr1/desk (~600 frames; the dataset itself is not available offline): 8 synthetic 640x480 DSO sequences
+    of 600 tracked frames through vors_trackers_* in the REFERENCE arithmetic against the oracle tracker — 4800 chained alignments with
+    ~25 keyframe switches per sequence, every pose identical bit for bit; FUSED on the same frames reported (sequences beyond 1e-4)."""
+    rows, cols, L, n_seq, n = 480, 640, 6, 8, 601
+    intr = O.INTRINSICS_FR1
+    frames, gh, dh = _dso_sequences(n_seq, n, rows, cols, intr, 4242)
+    ocfg = O.make_config(L, intr, candidates_mode=V.CANDIDATES_DSO)
+    ref = O.track_sequences(ocfg, gh, dh, n_threads=n_seq)
+    cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=V.CANDIDATES_DSO, arithmetic=V.ARITH_REFERENCE)
+    traj, stat, sw = _run_trackers(cfg, frames, n_seq, rows, cols)
+    assert (stat == ref["status"]).all() and (sw == ref["changed_keyframe"]).all()
+    assert (traj.view(np.uint32) == ref["poses"].view(np.uint32)).all(), f"max difference {np.abs(traj - ref['poses']).max():.3e}"
+    assert ref["changed_keyframe"].sum() >= 5 * n_seq
+    cfg.arithmetic = V.ARITH_FUSED
+    trajf, statf, _ = _run_trackers(cfg, frames, n_seq, rows, cols)
+    drift = np.abs(trajf - ref["poses"]).max(axis=2)          # [n_seq, frames]
+    print(f"FUSED over 600 frames: {(drift.max(axis=1) > POSE_TOL).sum()} of {n_seq} sequences leave the 1e-4 band; per-frame max drift "
+          f"at frames 100/300/600: {drift[:, 99].max():.2e} / {drift[:, 299].max():.2e} / {drift[:, 599].max():.2e}")
+    assert (statf == ref["status"]).all() and drift.max() < 2e-2
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["coarse_to_fine", "dense"])
