@@ -23,13 +23,23 @@ SUM_RTOL = 2e-5
 ARITH = V.ARITH_EXACT
 
 
-@pytest.fixture(autouse=True, params=[V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
+@pytest.fixture(autouse=True, params=[V.ARITH_EXACT, V.ARITH_FUSED, V.ARITH_REFERENCE], ids=["exact", "fused", "reference"])
 def arithmetic(request):
-    """EVERY test of this file runs in both per-point arithmetics: every handle below is configured through vcfg()."""
+    """EVERY test of this file runs in all three arithmetics: every handle below is configured through
+    vcfg(). In the REFERENCE arithmetic (the reference's summation order) iteration counts, models and poses are asserted EQUAL to the
+    oracle's, not close (exact_parity())."""
     global ARITH
     ARITH = request.param
     yield request.param
     ARITH = V.ARITH_EXACT
+
+
+def exact_parity():
+    return ARITH == V.ARITH_REFERENCE
+
+
+def obs_arith():  # the operator level knows EXACT (tree-order sums) and REFERENCE (sums in the order of the observations)
+    return V.ARITH_REFERENCE if exact_parity() else V.ARITH_EXACT
 
 
 def vcfg(L, intr, mode=0, thresh=7, huber=0.0):
@@ -107,7 +117,7 @@ def test_lm_eval_operator_vs_golden(path):
     cur_pyr = O.mean_pyramid(g["cur_gray"][0], L)
     for l in range(L):
         for tag, model in (("id", np.array([0, 0, 0, 0, 0, 0, 1], np.float32)), ("fin", g["models"][0])):
-            obs = V.Obs(g[f"k{l}"], g[f"img{l}"], cur_pyr[l], g[f"xy{l}"], g[f"iz{l}"], g[f"jac{l}"])
+            obs = V.Obs(g[f"k{l}"], g[f"img{l}"], cur_pyr[l], g[f"xy{l}"], g[f"iz{l}"], g[f"jac{l}"], arithmetic=obs_arith())
             e, n, gg, H, r = V.lm_eval(obs, model, want_residuals=True)
             assert n == int(g[f"ev_{tag}{l}_n"]), "inside set size"
             gr = g[f"ev_{tag}{l}_r"]
@@ -136,6 +146,9 @@ def test_track_pairs_vs_oracle(rows, cols, L, n, mode):
     # iteration counts may differ by a step when an accept/reject comparison is within rounding (reported, not required)
     same = (stats["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1).mean()
     print(f"[{cols}x{rows} L{L} mode{mode}] max pose err {err.max():.2e}, identical iteration counts in {same:.0%} of pairs")
+    if exact_parity():  # the reference's summation order: the oracle's LM path, decision for decision
+        assert (stats["nb_iter"][:, :L] == ref["nb_iter"]).all()
+        assert (bits(poses) == bits(ref["poses"])).all() and (bits(stats["optical_flow"]) == bits(ref["flow"])).all()
 
 
 def test_lm_solve_and_host_driven_trait_vs_oracle():
@@ -148,7 +161,7 @@ def test_lm_solve_and_host_driven_trait_vs_oracle():
     for l in range(L - 1, -1, -1):
         xy, iz, jac = tr.points(l)
         _, _, _, k = tr.level(l)
-        obs = V.Obs(k, tr.image(l), cur[l], xy, iz, jac)
+        obs = V.Obs(k, tr.image(l), cur[l], xy, iz, jac, arithmetic=obs_arith())
         st, m_dev, it_dev, e_dev, lam_dev = V.lm_solve(obs, model)               # whole loop on the device
         state, it_host = V.LMOptimizerState.iterative_solve(obs, model)          # trait-driven from the host
         ost, m_or, it_or, e_or, lam_or = O.lm_solve(k, tr.image(l), cur[l], xy, iz, jac, model)
@@ -157,6 +170,9 @@ def test_lm_solve_and_host_driven_trait_vs_oracle():
         # Iteration counts are reported, not required: at convergence the accept/reject comparison E_new > E_old is decided
         # by summation-order rounding, and a rejection keeps iterating (lambda x10) without moving the model.
         print(f"level {l}: nb_iter device {it_dev} host-driven {it_host} oracle {it_or}")
+        if exact_parity():
+            assert it_dev == it_host == it_or, f"level {l}: iteration counts {it_dev} / {it_host} / {it_or}"
+            assert (bits(m_dev) == bits(m_or)).all() and (bits(state.eval_data.model) == bits(m_or)).all()
         assert it_dev <= 21 and it_host <= 21
         assert rel_close(e_dev, e_or, 1e-4)
         model = m_or
@@ -348,6 +364,8 @@ def test_pose_parity_statistics_full_size():
         st = V.decode_stats(stats)
         same = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1).mean()
         print(f"mode {mode}: max {err.max():.2e} p99 {np.quantile(err, 0.99):.2e}; identical iteration counts {same:.0%}")
+        if exact_parity():
+            assert same == 1.0 and err.max() == 0.0
         assert (status.cpu().numpy() == ref["status"]).all()
         assert err.max() < POSE_TOL
         assert np.quantile(err, 0.99) < 2e-5
