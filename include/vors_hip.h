@@ -141,7 +141,8 @@ void vors_tracker_destroy(vors_tracker* t);
  *     (inverse_compositional.rs:177), the LM loop, the pose composition (:203-208), the optical-flow keyframe test (:211-224) and — for
  *     exactly the sequences whose flow reached the threshold — the promotion of the current frame to keyframe (:227-239:
  *     precompute_multires_data on the current pyramid and THIS call's depth map, keyframe_pose <- current_frame_pose). No host round
- *     trip, no synchronisation: a call only enqueues work on hip_stream. Results per sequence are bit-identical to a vors_tracker fed
+ *     trip, no synchronisation: init and track only enqueue work on hip_stream. (A trackers-owned batch keeps no pointer into the
+ *     caller's frames in the sparse modes: keyframe inspection through vors_batch_* is not available for it.) Results per sequence are bit-identical to a vors_tracker fed
  *     the same frames for handles of fewer than 512 sequences (tests/test_gpu_trackers.py); larger handles are scheduled differently
  *     (threads per sequence, evaluation rounds), which changes the ORDER of the f32 sums and with it the last bits, nothing else.
  *     Frames: DEVICE buffers, row-major, sequence s at offset s * rows * cols; they are read by the work this call enqueues and by
@@ -186,7 +187,8 @@ vors_status vors_track_pairs(const vors_config* cfg, int n_pairs, const uint8_t*
  * (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised: outputs are valid once the stream
  * reaches this point. Workspaces are allocated once at create() for up to max_pairs pairs. */
 typedef struct vors_batch vors_batch;
-/* Scheduling knobs (environment, read at create(); results stay within the stated tolerance whatever their value — they only
+/* Scheduling knobs (environment, read at create() — except VORS_DSO_SCAN, VORS_DSO_PLANES and VORS_PYRAMID_FUSED, which are read ONCE PER
+ * PROCESS, at the first keyframe stage / pyramid; results stay within the stated tolerance whatever their value — they only
  * change how the same arithmetic is spread over the chip; tests/test_gpu_parity.py covers the variants):
  *   VORS_LM_BLOCK=64..1024       threads per frame pair in the per-pair LM kernel (default by batch size and mode)
  *   VORS_LM_SPLIT=0              dense mode: one per-pair kernel for all levels instead of evaluation rounds

@@ -235,6 +235,29 @@ def test_sequences_failure_semantics_vs_oracle(mode):
     assert failed >= 2, "the scenario was meant to kill at least one sequence"
 
 
+@pytest.mark.parametrize("arith", [V.ARITH_EXACT, V.ARITH_FUSED], ids=["exact", "fused"])
+def test_dense_128_sequences_equal_single_trackers_beyond_the_chunk_cap(arith):
+    """The evaluation rounds cut a level-0 evaluation into chunks whose count fixes the order of the f32 partial sums; it must be the same
+    for EVERY handle below 512 sequences (it was 256 below 128 pairs and 128 from 128 on, equalised only by the S0 / 2400 cap
+    up to 640x480). 640x512 dense, 128 sequences in one lock-step handle against single trackers, bit for bit."""
+    rows, cols, L, n_seq, n_frames = 512, 640, 6, 128, 4
+    intr = O.scaled_intrinsics(rows, cols)
+    frames = make_sequences(n_seq, n_frames, rows, cols, intr, blocky=False)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=V.CANDIDATES_DENSE, arithmetic=arith)
+    many = V.Trackers(cfg, n_seq, rows, cols)
+    many.init(*frames[0])
+    pick = [0, 37, 127]
+    host = [(g[pick].cpu().numpy(), d[pick].cpu().numpy().view(np.uint16)) for g, d in frames]
+    singles = [cfg.init(0.0, host[0][1][j], 0.0, host[0][0][j]) for j in range(len(pick))]
+    for k in range(1, n_frames):
+        many.track(*frames[k])
+        poses, status, _ = many.current_frames()
+        for j, s_ in enumerate(pick):
+            assert singles[j].track(float(k), host[k][1][j], float(k), host[k][0][j]) == status[s_]
+            p1 = singles[j].current_frame()[1]
+            assert (p1.view(np.uint32) == poses[s_].view(np.uint32)).all(), f"frame {k} sequence {s_}: {np.abs(p1 - poses[s_]).max():.3e}"
+
+
 def test_device_frame_renderer_agrees_with_the_cpu_renderer():
     """vors_synth_render_frames (HIP, f64) and the oracle's CPU renderer evaluate the same scene function (csrc/synth_scene.h): the frames may
     differ only where a transcendental's last bit moves a value across a rounding boundary — a handful of pixels by one grey level / one

@@ -140,3 +140,45 @@ def test_vors_track_cli_config3_at_full_length_600_frames_dso_reference_arithmet
         assert out[k - 1][0] == repr(td)
         assert (got.view(np.uint32) == pose.view(np.uint32)).all(), f"frame {k}: {np.abs(got - pose).max():.3e}"
     assert switches >= 10
+
+
+@pytest.mark.gpu
+def test_vors_track_cli_stderr_lines_are_the_reference_s(tmp_path):
+    """Without --quiet the CLI prints what the reference's eprintln!s print, with Rust's float Display (shortest round-trip digits,
+    positional notation): `Optical_flow: {}` per tracked frame (inverse_compositional.rs:222) and `Changing keyframe after: {} seconds`
+    on a switch (:228-229, f64 difference of the depth timestamps). Checked against the oracle tracker in the REFERENCE arithmetic,
+    where the optical flow is bit-identical."""
+    _ensure_host_built()
+    rows, cols, n = 480, 640, 26
+    intr = O.INTRINSICS_FR1
+    os.makedirs(tmp_path / "depth")
+    os.makedirs(tmp_path / "rgb")
+    step = np.array([0.012, -0.006, 0.004, 0.002, -0.003, 0.001])
+    frames, lines = [], []
+    for k in range(n):
+        g, d = O.synth_frame(77, step * k, rows, cols, intr, frame_salt=k)
+        td, tc = 1305031102.160407 + 0.033 * k, 1305031102.175304 + 0.033 * k
+        _write_png(str(tmp_path / "depth" / f"{td:.6f}.png"), d)
+        _write_png(str(tmp_path / "rgb" / f"{tc:.6f}.png"), g)
+        lines.append(f"{td:.6f} depth/{td:.6f}.png {tc:.6f} rgb/{tc:.6f}.png")
+        frames.append((float(f"{td:.6f}"), d, float(f"{tc:.6f}"), g))
+    assoc = tmp_path / "associations.txt"
+    assoc.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([os.path.join(HOST, "vors_track"), "fr1", str(assoc), "--arith", "reference"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ot = O.Tracker(O.make_config(6, O.INTRINSICS_FR1), frames[0][0], frames[0][1], frames[0][2], frames[0][3])
+    expect, kf_t, switches = [], frames[0][0], 0
+    for k in range(1, n):
+        td, d, tc, g = frames[k]
+        st = ot.track(td, d, tc, g)
+        last = ot.last()
+        if st != 0:
+            expect.append("Error at Cholesky decomposition of hessian")
+        expect.append("Optical_flow: " + np.format_float_positional(np.float32(last["flow"]), unique=True, trim="-"))
+        if last["changed_keyframe"]:
+            expect.append("Changing keyframe after: " + np.format_float_positional(np.float64(td - kf_t), unique=True, trim="-") + " seconds")
+            kf_t = td
+            switches += 1
+    got = [l for l in r.stderr.splitlines() if l.strip()]
+    assert got == expect, "\n".join(f"{a!r} | {b!r}" for a, b in zip(got, expect) if a != b)
+    assert switches >= 1

@@ -363,7 +363,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         // evaluation rounds on the finest levels (lm_kernels.hip): chunks per pair so that large batches get ~16 workgroups per pair and
         // small ones (down to the single tracker) still spread one evaluation over the chip.
         // `chunks` = partial-sum slots per pair = the late-round cut (at least 512 pixels each); the full rounds use a quarter of it
-        int chunks = max_pairs >= 1024 ? 64 : (max_pairs >= 128 ? 128 : 256);
+        // (ONE count for every handle below 512 pairs: the chunk count fixes the order of the f32 partial sums, and a vors_tracker (N = 1)
+        // must stay bit-identical to a sequence of a lock-step handle of up to 511 sequences at every image size — the S0 / 2400 cap below
+        // only happened to equalise 128 and 256 up to 640x480)
+        int chunks = max_pairs >= 1024 ? 64 : (max_pairs >= 512 ? 128 : 256);
         chunks = std::max(4, std::min(chunks, g.S0 / 2400));  // (at least ~2400 pixels per chunk: 320x240 wants 32, not 64-150)
         if (const char* ev = getenv("VORS_LM_CHUNKS")) chunks = std::max(4, atoi(ev));
         b->split.chunks = chunks;
@@ -372,12 +375,18 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         for (int l = 0; l < g.L; ++l)
             if ((long long)g.lv[l].rows * g.lv[l].cols >= 65536) n_split = l + 1;
         b->split.n_split = getenv("VORS_LM_SPLIT_LEVELS") ? atoi(getenv("VORS_LM_SPLIT_LEVELS")) : std::max(1, n_split);
+        b->split.n_split = std::max(1, std::min(b->split.n_split, g.L));
+        // FUSED: a level of at most fused_exact_points pixels is evaluated in the EXACT arithmetic (include/vors_hip.h) — the per-pair kernel
+        // applies that rule, the evaluation rounds do not, so such levels are never solved by rounds (tiny images: no rounds at all)
+        if (g.arith == VORS_ARITH_FUSED)
+            while (b->split.n_split > 0 && g.lv[b->split.n_split - 1].rows * g.lv[b->split.n_split - 1].cols <= g.fused_exact_points) b->split.n_split -= 1;
         // rounds before the per-pair finish: a level solved by rounds needs >= 2 of them per evaluation pattern, so the count follows the
         // number of such levels (1280x960 has three: 10 rounds left 64 pairs 2.6x slower than 16)
         const int ns = b->split.n_split;
         b->split.rounds = getenv("VORS_LM_SPLIT_ROUNDS") ? atoi(getenv("VORS_LM_SPLIT_ROUNDS")) : (max_pairs >= 512 ? (ns <= 1 ? 12 : 26) : 4 * ns + 8);
         // (a lone dense pair would be 8 % faster with 2 * ns rounds, but a vors_tracker must stay bit-identical to a sequence of a
         // lock-step handle of up to 511 sequences: the same count for every handle below 512 pairs)
+        if (b->split.n_split == 0) b->split.chunks = 0;  // (split path off: launch_lm_track then runs the per-pair kernel for every level)
         if (e == hipSuccess) e = dmalloc(&b->split.state, np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
@@ -505,7 +514,7 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
 static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t* d_cur_gray, const float* d_prev_poses7,
                                        const float* d_kf_poses7, float* d_out_poses7, int32_t* d_out_status,
                                        vors_pair_stats* d_out_stats, hipStream_t s) {
-    if (!b->kf_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "track_current called before prepare_keyframes");
+    if (b->prepared_pairs <= 0) return fail(VORS_ERR_INVALID_ARGUMENT, "track_current called before prepare_keyframes");
     if (n_pairs > b->prepared_pairs)
         return fail(VORS_ERR_INVALID_ARGUMENT, "track_current: n_pairs (" + std::to_string(n_pairs) + ") exceeds the " +
                                                    std::to_string(b->prepared_pairs) + " keyframes prepared on this handle");
@@ -1164,14 +1173,18 @@ vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const ui
     }
     st = vors_batch_prepare_keyframes(b, t->n_seq, kf_gray, kf_depth, s);
     if (st != VORS_OK) return st;
+    if (b->g.mode != VORS_CANDIDATES_DENSE) {
+        // Sparse modes: everything later stages need is in the records; the caller may reuse or free its frames, and keyframe promotion
+        // (trackers_promote) rebuilds the records from later frames. The handle must not keep pointers into frames it does not own:
+        // the keyframe-inspection entry points (vors_batch_get_keyframe_image / get_points) are not available on a trackers-owned batch.
+        b->kf_level0 = nullptr;
+        b->kf_depth = nullptr;
+    }
     // first frame: keyframe_pose = current_frame_pose = identity (inverse_compositional.rs:86-99)
-    std::vector<float> ident(n * 7, 0.f);
-    for (size_t i = 0; i < n; ++i) ident[7 * i + 6] = 1.f;
-    HIP_TRY(hipMemcpyAsync(t->cur_poses.p, ident.data(), n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t->kf_poses.p, ident.data(), n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_identity_poses(t->cur_poses.as<float>(), t->kf_poses.as<float>(), t->n_seq, s);  // (on the device: init only enqueues work, like track)
     HIP_TRY(hipMemsetAsync(t->kf_frame.p, 0, n * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(t->status.p, 0, n * sizeof(int32_t), s));
-    HIP_TRY(hipStreamSynchronize(s));  // (`ident` is pageable host memory)
+    HIP_TRY(hipGetLastError());
     t->frame_index = 0;
     t->initialised = true;
     return VORS_OK;

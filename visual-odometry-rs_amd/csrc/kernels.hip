@@ -1018,6 +1018,17 @@ __global__ __launch_bounds__(256) void promote_copy_kernel(Geom g, const uint8_t
         for (size_t k = t; k < bytes && k < t + 16; ++k) dp[k] = sp[k];
     }
 }
+__global__ void identity_poses_kernel(float* __restrict__ a, float* __restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 7 * n) {
+        const float v = (i % 7 == 6) ? 1.0f : 0.0f;  // translation 0, quaternion (0, 0, 0, 1)
+        a[i] = v;
+        b[i] = v;
+    }
+}
+void launch_identity_poses(float* a, float* b, int n, hipStream_t s) {
+    hipLaunchKernelGGL(identity_poses_kernel, dim3((7 * n + 255) / 256), dim3(256), 0, s, a, b, n);
+}
 void launch_promote_copy(const Geom& g, const void* src, size_t src_stride, void* dst, size_t dst_stride, size_t bytes, int n_pairs,
                          hipStream_t s) {
     const int vec = (((uintptr_t)src | (uintptr_t)dst | src_stride | dst_stride) % 16 == 0) ? 1 : 0;

@@ -10,6 +10,8 @@
 // the reference panics.
 #pragma once
 #include <array>
+#include <charconv>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -22,6 +24,17 @@
 #include "optimizer.hpp"
 
 namespace vors {
+
+// Rust `{}` (Display) for floats: the shortest digits that round-trip, positional notation, `1.0` prints as `1`
+// (what eprintln!("Optical_flow: {}", ..) and the trajectory writer tum_rgbd.rs:78-85 produce).
+template <class T>
+inline std::string rust_display(T v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[512];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
 
 using Float = float;              // src/misc/type_aliases.rs:10
 using Iso3 = std::array<float, 7>;  // tx ty tz qx qy qz qw
@@ -93,6 +106,9 @@ class Tracker {  // inverse_compositional.rs:31-34
             throw std::invalid_argument("Tracker::track: frame shape differs from the keyframe's");
         if (depth_map.layout != layout_ || img.layout != layout_) throw std::invalid_argument("Tracker::track: layout differs from init's");
         int status = 0;
+        double keyframe_depth_timestamp = 0;
+        Iso3 keyframe_pose_before;
+        check(vors_tracker_keyframe(h_, &keyframe_depth_timestamp, keyframe_pose_before.data()));
         check(vors_tracker_track_checked(h_, depth_time, depth_map.data, img_time, img.data, img.rows, img.cols, &status));
         vors_pair_stats s;
         check(vors_tracker_last_stats(h_, &s));
@@ -100,8 +116,10 @@ class Tracker {  // inverse_compositional.rs:31-34
         last_status_ = status;
         if (log_) {
             if (status != VORS_TRACK_OK) std::fprintf(stderr, "Error at Cholesky decomposition of hessian\n");  // :196
-            std::fprintf(stderr, "Optical_flow: %g\n", s.optical_flow);                                       // :222
-            if (s.change_keyframe) std::fprintf(stderr, "Changing keyframe\n");                                // :229
+            // the reference's own lines, with Rust's float Display (inverse_compositional.rs:222,228-229)
+            std::fprintf(stderr, "Optical_flow: %s\n", rust_display(s.optical_flow).c_str());
+            if (s.change_keyframe)
+                std::fprintf(stderr, "Changing keyframe after: %s seconds\n", rust_display(depth_time - keyframe_depth_timestamp).c_str());
         }
     }
     // Tracker::current_frame (inverse_compositional.rs:243-248): (depth timestamp, pose)

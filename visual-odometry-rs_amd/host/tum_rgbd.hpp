@@ -30,15 +30,7 @@ struct Frame {  // tum_rgbd.rs:55-61
     Iso3 pose;
 };
 
-// Rust `{}` for floats.
-template <class T>
-inline std::string rust_display(T v) {
-    if (std::isnan(v)) return "NaN";
-    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
-    char buf[512];
-    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
-    return std::string(buf, r.ptr);
-}
+using vors::rust_display;  // Rust `{}` for floats (tracker.hpp)
 
 // tum_rgbd.rs:78-85
 inline std::string to_string(const Frame& f) {

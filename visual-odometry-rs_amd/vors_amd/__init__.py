@@ -559,8 +559,14 @@ class Pipeline:
         ticket = C.c_int64(-1)
         st = lib().vors_pipeline_submit(self._h, n, Batch._dp(kf_gray), Batch._dp(kf_depth), Batch._dp(cur_gray), Batch._dp(prev_poses7),
                                         Batch._dp(out_poses7), Batch._dp(out_status), Batch._dp(out_stats), Batch._stream(), C.byref(ticket))
-        # the step reads and writes these buffers until it completes: keep them alive for as long as its slot can be running it
-        self._refs[ticket.value % self.depth] = (kf_gray, kf_depth, cur_gray, out_poses7, out_status, out_stats, prev_poses7)
+        # the step reads and writes these buffers until it completes: keep them alive for as long as its slot can be running it. A call
+        # that failed before it was given a ticket touches no slot's references (ticket -1 would otherwise evict those of slot depth - 1
+        # while that slot's step may still be running); its buffers are kept aside instead.
+        refs = (kf_gray, kf_depth, cur_gray, out_poses7, out_status, out_stats, prev_poses7)
+        if ticket.value >= 0:
+            self._refs[ticket.value % self.depth] = refs
+        else:
+            self._refs.setdefault("failed", []).append(refs)
         _check(st)
         return ticket.value
 
