@@ -165,6 +165,30 @@ def test_bench_two_ranks_code_path_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_strong_scaling_of_a_fixed_batch():
+    """BASELINE configs[3] as written is a FIXED batch sharded over the GPUs (4096 pairs over 8): `--scaling strong --total-pairs T` gives
+    every rank ceil(T / N) pairs of the SAME global batch (seeds = global pair indices) and reports T pairs per step whatever N is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--candidates", "c2f", "--scaling", "strong", "--total-pairs", "96", "--no-secondary", "--no-pmc",
+              "--no-sequences", "--cpu-pairs", "0", "--parity-pairs", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d1 = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    for d, n, per in ((d1, 1, 96), (d2, 2, 48)):
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["pairs_per_gpu"] == per and d["config"]["total_pairs"] == 96
+        assert abs(d["value"] - 96 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # the fixed batch per step, whatever N
+    assert d2["self_check"]["gathered_blocks_equal_owners"]
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_json_contract():
     """The ONE JSON line of `python bench.py` (N = 1) carries every key the driver's contract names, with the contract's vocabulary
     (roofline.bound in {hbm, mfma}; cpu_baseline.kind in {reference, port}), and its numbers are self-consistent."""

@@ -435,7 +435,9 @@ def test_batch_keyframe_reuse_and_stream_capture():
 BLOCKY = 1 << 63  # seeds with the top bit set render the piecewise-constant texture (synth_scene.h)
 
 
-@pytest.mark.parametrize("rows,cols,L,n", [(480, 640, 6, 4), (240, 320, 5, 3), (250, 331, 4, 2), (120, 160, 4, 3), (60, 80, 3, 2)])
+# (250x331 and 252x332 go through dso_gradmag_median_kernel — the one-wavefront-per-region form for widths that are not multiples of 16 —
+# with byte and with dword loads; the others through the strip kernel)
+@pytest.mark.parametrize("rows,cols,L,n", [(480, 640, 6, 4), (240, 320, 5, 3), (250, 331, 4, 2), (252, 332, 4, 2), (120, 160, 4, 3), (60, 80, 3, 2)])
 def test_dso_candidates_vs_oracle(rows, cols, L, n):
     """candidates_mode = 2: DSO-style selection (dso.rs + examples/candidates_dso.rs parameters) as the level-0 mask source.
     The smaller sizes push the candidate ratio outside [0.8, 4] (recursive rounds with an adapted block size) or into
