@@ -72,6 +72,7 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     g->huber_delta = cfg->huber_delta;
     g->fused_exact_points = getenv("VORS_FUSED_EXACT_POINTS") ? atoi(getenv("VORS_FUSED_EXACT_POINTS")) : VORS_FUSED_EXACT_POINTS_DEFAULT;
     g->fused_exact_step = getenv("VORS_FUSED_EXACT_STEP") ? atoi(getenv("VORS_FUSED_EXACT_STEP")) : 0;
+    g->fused_small_warp = (getenv("VORS_FUSED_SMALL") && std::string(getenv("VORS_FUSED_SMALL")) == "exact") ? 0 : 1;
     g->S0 = rows * cols;
     int r = rows, c = cols;
     Intr k{cfg->cu, cfg->cv, cfg->fu, cfg->fv, cfg->skew};

@@ -403,6 +403,7 @@ struct ImgCtx {
     double inv_fu_d, inv_fv_d;    // level constants of the fused arithmetic (engine.h LevelGeom), 0 = form them here
     float inv_fu, inv_fv, s_fuv;
     bool force_exact = false;     // FUSED kernels: evaluate this level in the EXACT arithmetic (workgroup-uniform)
+    bool exact_warp = false;      // FUSED kernels, candidate lists: (u, v) of this level from the reference's warp chain, the rest fused
     bool exact_step = false;      // FUSED kernels: step() with lm_step instead of lm_step_fast at this level
 };
 
@@ -619,9 +620,7 @@ struct FUnit {
     uint32_t tmw;               // template grey levels, one byte per point
     float gu[G], gv[G];         // integer gradients as floats (zero on the level-0 border); not set for energy-only evaluations
     bool valid[G];
-#if VORS_ABL_EXACT_WARP
-    float px[G], py[G];         // pixel coordinates (ablation: the reference's warp chain)
-#endif
+    float px[G], py[G];         // pixel coordinates (only set / read where the reference's warp chain is evaluated: XW instantiations)
 };
 // What stage C (bilinear, residual, Jacobian, sums) needs of a unit whose taps are in flight.
 // What bounds this loop (round 2, per-kernel probes with tools/lm_variants.sh at 4096 pairs, level-0 rounds):
@@ -652,8 +651,13 @@ __device__ __forceinline__ float cvt_ubyte(W w) {  // float(byte BYTE of w): one
     return f;
 }
 // Stage B: warp (see the header of this section) + inside test + tap requests.
-template <bool ENERGY_ONLY, int G>
-__device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st, const Iso& model) {
+// XW: (u, v) from the reference's own chain — back_project (with the verified fast divisions by the focal lengths), Iso3 * point, project,
+// two IEEE divisions by z' (lm_optimizer.rs:213-219) — instead of the homography form; everything after (u, v) stays fused. This is what
+// the levels of FEW points of the candidate-list modes run (ImgCtx::exact_warp): ~150 instead of ~226 instructions per point
+// of the full EXACT evaluation, with the same parity statistic (profiles/r03_parity_ablation.md, build `warp`; re-measured in round 4).
+template <bool ENERGY_ONLY, bool XW = false, int G>
+__device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c, const FusedCtx& f, FusedStage<G>& st, const Iso& model,
+                                              const FastDiv& dfu = FastDiv{1.f, 1.f, 0}, const FastDiv& dfv = FastDiv{1.f, 1.f, 0}) {
     // gfx950 issues v_fma / v_mul / v_add / shifts every ~2.6 cycles but conversions, compares, selects, v_floor and v_fract every ~4.4
     // and v_rcp every ~8.9 (tools/ubench/valu_ops): floor-to-integer in ONE conversion (v_cvt_flr_i32_f32), the fractional part in one
     // v_fract, and the window test as two unsigned integer compares instead of four float ones.
@@ -671,13 +675,13 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
     for (int g = 0; g < G; ++g) u[g] = hu[g] * rz[g];
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = hv[g] * rz[g];
-#if VORS_ABL_EXACT_WARP
+    if (XW || VORS_ABL_EXACT_WARP) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const V3 P = back_project(c.k, p.px[g], p.py[g], 1.0f / p.iz[g]);
-        project_uv(c.k, iso_transform_point(model, P), &u[g], &v[g]);
+        for (int g = 0; g < G; ++g) {
+            const V3 P = XW ? back_project_rt(IntrFast{c.k, dfu, dfv}, p.px[g], p.py[g], 1.0f / p.iz[g]) : back_project(c.k, p.px[g], p.py[g], 1.0f / p.iz[g]);
+            project_uv(c.k, iso_transform_point(model, P), &u[g], &v[g]);
+        }
     }
-#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu[g]) : "v"(u[g]));  // (int)floor(u), saturating
 #pragma unroll
@@ -826,9 +830,7 @@ struct FusedPixSrc : DenseSrc<LEVEL0> {  // one pixel per unit, any width
         p.tmw = (uint32_t)r.tm;
         p.gu[0] = (float)r.gx;
         p.gv[0] = (float)r.gy;
-#if VORS_ABL_EXACT_WARP
         p.px[0] = xf; p.py[0] = yf;
-#endif
     }
 };
 template <bool LEVEL0>
@@ -857,10 +859,8 @@ struct FusedQuadSrc : DenseQuadSrc<LEVEL0, false> {  // four horizontally adjace
         p.bv[0] = bv0; p.bv[1] = bv0 + f.h10; p.bv[2] = bv0 + f.h10_2; p.bv[3] = bv0 + f.h10_3;
         p.bz[0] = bz0; p.bz[1] = bz0 + f.h20; p.bz[2] = bz0 + f.h20_2; p.bz[3] = bz0 + f.h20_3;
         p.tmw = l.cw;
-#if VORS_ABL_EXACT_WARP
 #pragma unroll
         for (int j = 0; j < 4; ++j) { p.px[j] = x0f + (float)j; p.py[j] = yf; }
-#endif
         const int rows = this->rows, cols = this->cols;
         if (LEVEL0) {
             float dzf[4], rd[4];
@@ -945,9 +945,7 @@ struct FusedSlimSrc : SlimSrc {  // compact 12-byte candidate lists, two points 
             p.iz[g] = r.r[g].iz;  // always a known inverse depth: the lists hold candidates only
             p.gu[g] = (float)slim_gx(r.r[g].tg);
             p.gv[g] = (float)slim_gy(r.r[g].tg);
-#if VORS_ABL_EXACT_WARP
             p.px[g] = xf[g]; p.py[g] = yf[g];
-#endif
         }
     }
 };
@@ -1011,9 +1009,25 @@ __device__ __forceinline__ void eval_accumulate(const Src& src, int n_units, con
                                                                                nullptr, first);
             return;
         }
-        const FusedCtx f = pre ? load_fused_ctx(pre) : make_fused_ctx(c, model);  // (`pre` is a compile-time fact at every call site)
         const JacK jk = make_jack(c);
         int cnt = 0;  // inside points seen by this lane
+        if constexpr (std::is_same<Src, FusedSlimSrc>::value) {
+            if (c.exact_warp) {  // (workgroup-uniform) a level of few points: the reference's warp chain, the rest fused
+                const FusedCtx f{};  // (the homography is not used)
+                for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
+                    typename Src::Raw raw;
+                    src.template fetch<BLOCK>(cur, n_units, raw);
+                    FUnit<Src::G> un;
+                    src.template funit<ENERGY_ONLY>(raw, f, un);
+                    FusedStage<Src::G> st;
+                    fused_stage_b<ENERGY_ONLY, true>(un, c, f, st, model, src.fu, src.fv);
+                    fused_stage_c<HUBER, ENERGY_ONLY>(c, jk, st, acc, cnt);
+                }
+                acc[1] = (float)cnt;
+                return;
+            }
+        }
+        const FusedCtx f = pre ? load_fused_ctx(pre) : make_fused_ctx(c, model);  // (`pre` is a compile-time fact at every call site)
         for (typename Src::Cursor cur = src.template begin<BLOCK>(first); cur.i < n_units; cur = src.template advance<BLOCK>(cur)) {
             typename Src::Raw raw;
             src.template fetch<BLOCK>(cur, n_units, raw);
@@ -1221,6 +1235,12 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
             }
         Iso cand;
         bool ok;
+#ifdef VORS_DEV_SOLVE_REPEAT  // (development probe: how much of an evaluation's latency is the one-lane step)
+        for (int rep = 1; rep < VORS_DEV_SOLVE_REPEAT; ++rep) {
+            Iso tmp;
+            if (lm_step_fast(h, g, model, lm_coef + (float)rep * 1e-30f, &tmp)) h[0] += tmp.t.x * 1e-30f;
+        }
+#endif
         if constexpr (FAST && !VORS_ABL_EXACT_STEP) {
             if (exact_step) ok = lm_step(h, g, model, lm_coef, &cand);  // (uniform; Geom::fused_exact_step, a development knob)
             else ok = lm_step_fast(h, g, model, lm_coef, &cand);
@@ -1511,8 +1531,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             // thousand points on it averages out below that noise. (Workgroup-uniform.)
             const int npts = DENSE ? g.lv[lvl].rows * g.lv[lvl].cols
                                    : __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]);
-            c.force_exact = npts <= g.fused_exact_points;
-            c.exact_step = c.force_exact && g.fused_exact_step != 0;
+            const bool few = npts <= g.fused_exact_points;
+            // candidate lists: the reference's warp chain alone (Geom::fused_small_warp, the default); dense pixels levels (and
+            // VORS_FUSED_SMALL=exact): the whole EXACT evaluation
+            c.exact_warp = few && !DENSE && g.fused_small_warp != 0;
+            c.force_exact = few && !c.exact_warp;
+            c.exact_step = few && g.fused_exact_step != 0;
         }
         int nb_iter = 0, n_full = 0;
         float energy = 0.f, lm_coef = 0.f;
