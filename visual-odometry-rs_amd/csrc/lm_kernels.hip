@@ -1259,7 +1259,13 @@ __device__ __forceinline__ void solve_step_lane0(LmShared& s, int cur, const Iso
 // (inverse_compositional.rs:195-199).
 template <int BLOCK, bool HUBER, class Src>
 __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* model, int* nb_iter_out, float* energy_out,
-                            float* lm_coef_out, LmShared& s, const LmSplitState* resume = nullptr, int* n_full_out = nullptr) {
+                            float* lm_coef_out, LmShared& s, const LmSplitState* resume = nullptr, int* n_full_out = nullptr, long long* ph = nullptr) {
+#ifdef VORS_PROFILE_PHASES  // (development probe: shader-clock cycles of a level spent in the point loop / the reduction / the one-lane step)
+#define VORS_PH(k) do { const long long t_now = clock64(); if (ph) ph[k] += t_now - t_ph; t_ph = t_now; } while (0)
+    long long t_ph = clock64();
+#else
+#define VORS_PH(k) do { } while (0)
+#endif
     float acc[NACC];
     Iso cur_model = *model;
     int cur = 0;
@@ -1288,14 +1294,19 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
             have_cand = false;
         }
     } else {
+        VORS_PH(3);
         eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cur_model, acc, nullptr);  // init: lm_optimizer.rs:113-118
+        VORS_PH(0);
         block_reduce<BLOCK>(acc, s, cur);
+        VORS_PH(1);
         cur_energy = uniform_f(s.sums[cur][0] / s.sums[cur][1]);  // energy_sum / residuals.len(): 0/0 = NaN like the reference
     }
     for (;;) {
         if (!have_cand) {
             nb_iter += 1;
+            VORS_PH(3);
             solve_step_lane0<Src::FUSED>(s, cur, cur_model, lm_coef, c.exact_step);  // step(): lm_optimizer.rs:123-136
+            VORS_PH(2);
             if (uniform_f(s.cand[7]) == 0.0f) return false;
             cand = iso_uniform(iso_load(s.cand));  // workgroup-uniform: keep it in scalar registers
         }
@@ -1326,8 +1337,11 @@ __device__ bool solve_level(const Src& src, int n_slots, const ImgCtx& c, Iso* m
                 continue;
             }
         }
+        VORS_PH(3);
         eval_accumulate<BLOCK, HUBER, false>(src, n_slots, c, cand, acc, nullptr);  // eval(): lm_optimizer.rs:140-149
+        VORS_PH(0);
         block_reduce<BLOCK>(acc, s, 1 - cur);
+        VORS_PH(1);
         const float energy = uniform_f(s.sums[1 - cur][0] / s.sums[1 - cur][1]);
         if (energy > cur_energy) {                      // Err(energy)
             if (too_many_iterations) break;
@@ -1546,7 +1560,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         const long long c_level0 = clock64();
 #endif
         with_level_source<DENSE, true, FUSED>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n_slots) {
+#ifdef VORS_PROFILE_PHASES
+            long long ph[4] = {0, 0, 0, 0};
+            ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr, &n_full, ph);
+            if (out_stats && threadIdx.x == 0 && lvl == VORS_PROFILE_PHASES) {  // phases of ONE level, cycles: loop, reduce, step, other
+                out_stats[pair].n_points[VORS_MAX_LEVELS - 2] = (int)ph[0];
+                out_stats[pair].n_points[VORS_MAX_LEVELS - 1] = (int)ph[1];
+                out_stats[pair].nb_iter[VORS_MAX_LEVELS - 2] = (int)ph[2];
+                out_stats[pair].nb_iter[VORS_MAX_LEVELS - 1] = (int)ph[3];
+            }
+#else
             ok = solve_level<BLOCK, HUBER>(src, n_slots, c, &lm_model, &nb_iter, &energy, &lm_coef, s, lvl == start_lvl ? resume : nullptr, &n_full);
+#endif
         });
         if (out_stats && threadIdx.x == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
@@ -1676,6 +1701,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             block_sum2<BLOCK>(n, dummy, s);
             if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = (int)n;
         }
+#ifndef VORS_PROFILE_PHASES
         if (threadIdx.x == 0)
             for (int lvl = g.L; lvl < VORS_MAX_LEVELS; ++lvl) {
                 out_stats[pair].nb_iter[lvl] = 0;
@@ -1683,6 +1709,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                 out_stats[pair].n_points[lvl] = 0;
                 out_stats[pair].energy[lvl] = 0.f;
             }
+#endif
 #ifdef VORS_PROFILE_LEVELS
         if (threadIdx.x == 0 && g.L <= VORS_MAX_LEVELS - 2) {
             out_stats[pair].energy[VORS_MAX_LEVELS - 2] = (float)(wall_clock64() - t_epilogue0) * 0.01f;  // epilogue, microseconds
@@ -1779,20 +1806,30 @@ lm_split_eval_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __
 // One wavefront per active pair: chunk partials -> sums, then LMOptimizerState::eval's verdict + stop_criterion + the next
 // step() (lm_optimizer.rs:123-192), exactly as solve_level sequences them; a finished level hands over to the next one
 // (statistics, inverse_compositional.rs:190-200). Pairs that continue are appended to the next round's list.
-__global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
-                                                           int next_late) {
-    __shared__ float red[32];
+// STEP_WAVES pairs per workgroup, one wavefront each: their appends to the next round's list share ONE atomic per kind and workgroup —
+// with a workgroup per pair the 4096 same-address atomics of a full round were the kernel (55 us; ~13 ns apiece).
+// (The late rounds concern a handful of pairs and are latency: one pair per workgroup there.)
+template <int STEP_WAVES>
+__global__ __launch_bounds__(64 * STEP_WAVES) void lm_split_step_kernel(Geom g, LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
+                                                                        int next_late) {
+    __shared__ float red_all[STEP_WAVES][32];
+    __shared__ int s_kind[STEP_WAVES], s_base[2];
     const int n_active = split_n_active(ws, round);
-    for (int a = blockIdx.x; a < n_active; a += gridDim.x) {
-        const int pair = split_active(ws, round, a);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* red = red_all[wave];
+    for (int a0 = blockIdx.x * STEP_WAVES; a0 < n_active; a0 += gridDim.x * STEP_WAVES) {
+        const int a = a0 + wave;
+        const bool live = a < n_active;
+        int append_kind = -1;  // -1: the pair does not go on; 0: full evaluation next; 1: energy-only evaluation next
+        const int pair = split_active(ws, round, live ? a : 0);
         LmSplitState* st = ws.state + pair;
         const int lvl = st->lvl;
         const int chunks = split_chunks(ws, lvl);
         const int phase = st->phase;
         const bool have_full = phase != 1 || late;  // an energy-only round wrote the first two sums only
         const int n_sums = have_full ? NACC : 2;
-        if (threadIdx.x < n_sums) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
-            const float* pp = ws.partials + (size_t)pair * ws.chunks * 32 + threadIdx.x;
+        if (live && lane < n_sums) {  // chunks in index order; the loads of a batch of 8 are independent, the additions stay sequential
+            const float* pp = ws.partials + (size_t)pair * ws.chunks * 32 + lane;
             float t = 0.f;
             int ch = 0;
             for (; ch + 8 <= chunks; ch += 8) {
@@ -1803,10 +1840,10 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws,
                 for (int q = 0; q < 8; ++q) t += v[q];
             }
             for (; ch < chunks; ++ch) t += pp[ch * 32];
-            red[threadIdx.x] = t;
+            red[lane] = t;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (live && lane == 0) {
             const float energy = red[0] / red[1];  // energy_sum / residuals.len(): 0/0 = NaN like the reference
             Iso cur_model = iso_load(st->model);
             float lm_coef = st->lm_coef, cur_energy = st->cur_energy;
@@ -1905,14 +1942,35 @@ __global__ __launch_bounds__(64) void lm_split_step_kernel(Geom g, LmSplitWs ws,
             // FUSED arithmetic: the context of the evaluation this pair is due next, for all its workgroups (engine.h LmSplitState::fctx)
             if (again && g.arith == VORS_ARITH_FUSED) store_fused_ctx(g, st->lvl, iso_load(st->phase == 1 ? st->cand : st->model), st);
             // a candidate goes to the energy-only launch of the next round, unless that round is a late one (full evaluations only)
-            if (again) split_append(ws, round + 1, st->phase == 1 && !next_late, pair);
+            if (again) append_kind = (st->phase == 1 && !next_late) ? 1 : 0;
+        }
+        if (lane == 0) s_kind[wave] = append_kind;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // one reservation per kind for the whole workgroup
+            int n_full = 0, n_energy = 0;
+            for (int w = 0; w < STEP_WAVES; ++w) {
+                n_full += s_kind[w] == 0 ? 1 : 0;
+                n_energy += s_kind[w] == 1 ? 1 : 0;
+            }
+            s_base[0] = n_full ? atomicAdd(&ws.count[round + 1], n_full) : 0;
+            s_base[1] = n_energy ? atomicAdd(&ws.count[SPLIT_COUNT_STRIDE + round + 1], n_energy) : 0;
+        }
+        __syncthreads();
+        if (lane == 0 && append_kind >= 0) {
+            int rank = 0;
+            for (int w = 0; w < wave; ++w) rank += s_kind[w] == append_kind ? 1 : 0;
+            if (append_kind == 1) ws.list[(round + 1) & 1][ws.cap - 1 - (s_base[1] + rank)] = pair;
+            else ws.list[(round + 1) & 1][s_base[0] + rank] = pair;
         }
         __syncthreads();
     }
 }
 
 void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(lm_split_step_kernel, dim3(grid), dim3(64), 0, s, g, ws, out_stats, round, late, next_late);
+    if (grid >= 1024 && !late)
+        hipLaunchKernelGGL(lm_split_step_kernel<8>, dim3((grid + 7) / 8), dim3(512), 0, s, g, ws, out_stats, round, late, next_late);
+    else
+        hipLaunchKernelGGL(lm_split_step_kernel<1>, dim3(grid), dim3(64), 0, s, g, ws, out_stats, round, late, next_late);
 }
 #else
 // host-side launcher of the (arithmetic-independent) step kernel, defined in the exact object
@@ -2013,7 +2071,8 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
         // every pair needs at least two evaluations per level: full grids. Later rounds concern fewer and fewer pairs, finally a
         // handful of stragglers whose evaluations are pure latency: they are cut into 4x more chunks and get small grids
         // (grid-stride loops keep any count correct).
-        const int late_from = 2 * split.n_split + 2;
+        static const int late_env = getenv("VORS_LM_LATE_FROM") ? atoi(getenv("VORS_LM_LATE_FROM")) : -1;  // (development knob)
+        const int late_from = late_env >= 0 ? late_env : 2 * split.n_split + 2;
         const int late = r >= late_from, next_late = r + 1 >= late_from;
         split.chunks0 = late ? split.chunks : base_chunks;
         const int full = n_pairs * split.chunks0;
