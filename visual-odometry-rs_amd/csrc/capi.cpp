@@ -176,6 +176,11 @@ static void batch_free(vors_batch* b) {
     if (b->rec.V) (void)hipFree(b->rec.V);
     if (b->rec.LUT) (void)hipFree(const_cast<float2*>(b->rec.LUT));
     if (b->owns_sort_tmp && b->rec.sort_tmp) (void)hipFree(b->rec.sort_tmp);
+    if (b->split.side_stream) (void)hipStreamDestroy(b->split.side_stream);
+    if (b->split.ev_fork) (void)hipEventDestroy(b->split.ev_fork);
+    if (b->split.ev_join) (void)hipEventDestroy(b->split.ev_join);
+    if (b->split.side_list) (void)hipFree(b->split.side_list);
+    if (b->split.join_list) (void)hipFree(b->split.join_list);
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state, b->dso.pick_list,
                      b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used, b->rec.S, b->rec.stage, b->rec.region_cnt,
                      b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
@@ -392,8 +397,24 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->split.partials, np * chunks * 32, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[0], np, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->split.list[1], np, &b->bytes);
-        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)2 * (VORS_SPLIT_MAX_ROUNDS + 2), &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->split.count, (size_t)SPLIT_COUNT_INTS, &b->bytes);
         b->split.cap = max_pairs;
+        b->split.side_round = -1;
+        // side lane for the level-1 stragglers of a LARGE batch (engine.h LmSplitWs): two levels solved by rounds, >= 2048 pairs — the rounds
+        // of a smaller batch are short enough for the stragglers to keep up (measured: 512 pairs 2.21 -> 2.35 ms, 1024 pairs 3.76 -> 3.81 ms
+        // with it, 4096 pairs 12.3 -> 11.9 ms); VORS_LM_SIDE=0 turns it off, VORS_LM_SIDE=1 forces it from 512 pairs on
+        const int side_from = (getenv("VORS_LM_SIDE") && atoi(getenv("VORS_LM_SIDE")) == 1) ? 512 : 2048;
+        if (b->split.chunks > 0 && b->split.n_split == 2 && max_pairs >= side_from && !(getenv("VORS_LM_SIDE") && atoi(getenv("VORS_LM_SIDE")) == 0)) {
+            if (e == hipSuccess) e = dmalloc(&b->split.side_list, np, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&b->split.join_list, np, &b->bytes);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->split.side_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->split.ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->split.ev_join, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                b->split.side_round = 1;
+                if (!getenv("VORS_LM_SPLIT_ROUNDS")) b->split.rounds = 10;  // (the long tail of rounds was theirs; measured 8 / 10 / 12 / 16 / 26 at 4096 pairs)
+            }
+        }
     }
     float2* lut = nullptr;
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DENSE) {

@@ -138,7 +138,20 @@ struct LmSplitWs {
     int chunks0;          // chunks per pair at level 0 in this launch (level l: chunks0 >> 2l), <= chunks
     int n_split;          // levels 0 .. n_split-1 are solved this way
     int rounds;
+    // SIDE LANE (large dense batches, two levels solved by rounds): the few pairs still iterating at level 1 once everybody else has moved on
+    // to level 0 would get ONE cheap evaluation per round while each round lasts milliseconds (level-0 evaluations of 4096 pairs), and then
+    // keep ~20 more rounds alive on their own. After round `side_round` the step kernel hands them to a per-pair kernel on a second stream
+    // (one 1024-thread workgroup each, all their remaining level-1 iterations back to back, concurrent with the level-0 rounds of the
+    // others); they join the rounds again at level 0 (`join_list`, merged into a later round's list).
+    int side_round;       // -1: off
+    int* side_list;       // [cap] pairs handed to the side lane;  count[SPLIT_SIDE_COUNT] of them
+    int* join_list;       // [cap] pairs that finished level 1 there; count[SPLIT_JOIN_COUNT] of them
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
 };
+#define SPLIT_SIDE_COUNT (2 * (VORS_SPLIT_MAX_ROUNDS + 2))
+#define SPLIT_JOIN_COUNT (2 * (VORS_SPLIT_MAX_ROUNDS + 2) + 1)
+#define SPLIT_COUNT_INTS (2 * (VORS_SPLIT_MAX_ROUNDS + 2) + 2)
 
 // Per-pixel inverse-depth planes of the generic-mask keyframe path (all levels).
 struct PixelPlanes {

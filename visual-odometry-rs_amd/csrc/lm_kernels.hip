@@ -1511,6 +1511,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
         if ((int)blockIdx.x >= split_n_active(split, split.rounds)) return;
         pair = __builtin_amdgcn_readfirstlane(split_active(split, split.rounds, blockIdx.x));
     }
+    if (mode == 4) {  // side lane (engine.h LmSplitWs): workgroup k finishes the levels above 0 of the k-th pair handed over by the step kernel
+        if ((int)blockIdx.x >= split.count[SPLIT_SIDE_COUNT]) return;
+        pair = __builtin_amdgcn_readfirstlane(split.side_list[blockIdx.x]);
+    }
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
@@ -1529,7 +1533,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
             lm_model = iso_uniform(iso_load(st->model));
         }
     }
-    for (int lvl = start_lvl; lvl >= (mode == 1 ? split.n_split : 0); --lvl) {
+    for (int lvl = start_lvl; lvl >= (mode == 1 ? split.n_split : (mode == 4 ? 1 : 0)); --lvl) {
         ImgCtx c;
         c.img = level_ptr(g, cur0, curu, pair, lvl);
         c.rows = g.lv[lvl].rows;
@@ -1594,6 +1598,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VORS_LM_W
                 }
             break;
         }
+    }
+    if (mode == 4) {  // level 0 is the rounds' again: hand the pair over like mode 1 does
+        if (threadIdx.x == 0) {
+            LmSplitState* st = split.state + pair;
+            iso_store(lm_model, st->model);
+            st->went_well = went_well ? 1 : 0;
+            if (went_well) {
+                iso_store(lm_model, st->entry);
+                st->lvl = 0;
+                st->phase = 0;
+                st->nb_iter = 0;
+                st->n_full = 0;
+                if (FUSED) store_fused_ctx(g, 0, lm_model, st);
+                split.join_list[atomicAdd(&split.count[SPLIT_JOIN_COUNT], 1)] = pair;
+            } else {
+                st->phase = 2;
+            }
+        }
+        return;
     }
     if (mode == 3) {  // hand the finished pair back to the bookkeeping of mode 2
         if (threadIdx.x == 0) {
@@ -1813,7 +1836,7 @@ template <int STEP_WAVES>
 __global__ __launch_bounds__(64 * STEP_WAVES) void lm_split_step_kernel(Geom g, LmSplitWs ws, vors_pair_stats* __restrict__ out_stats, int round, int late,
                                                                         int next_late) {
     __shared__ float red_all[STEP_WAVES][32];
-    __shared__ int s_kind[STEP_WAVES], s_base[2];
+    __shared__ int s_kind[STEP_WAVES], s_base[3];
     const int n_active = split_n_active(ws, round);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* red = red_all[wave];
@@ -1942,30 +1965,39 @@ __global__ __launch_bounds__(64 * STEP_WAVES) void lm_split_step_kernel(Geom g, 
             // FUSED arithmetic: the context of the evaluation this pair is due next, for all its workgroups (engine.h LmSplitState::fctx)
             if (again && g.arith == VORS_ARITH_FUSED) store_fused_ctx(g, st->lvl, iso_load(st->phase == 1 ? st->cand : st->model), st);
             // a candidate goes to the energy-only launch of the next round, unless that round is a late one (full evaluations only)
-            if (again) append_kind = (st->phase == 1 && !next_late) ? 1 : 0;
+            if (again) append_kind = (round == ws.side_round && st->lvl > 0) ? 2 : ((st->phase == 1 && !next_late) ? 1 : 0);  // 2: side lane
         }
         if (lane == 0) s_kind[wave] = append_kind;
         __syncthreads();
         if (threadIdx.x == 0) {  // one reservation per kind for the whole workgroup
-            int n_full = 0, n_energy = 0;
+            int n_full = 0, n_energy = 0, n_side = 0;
             for (int w = 0; w < STEP_WAVES; ++w) {
                 n_full += s_kind[w] == 0 ? 1 : 0;
                 n_energy += s_kind[w] == 1 ? 1 : 0;
+                n_side += s_kind[w] == 2 ? 1 : 0;
             }
             s_base[0] = n_full ? atomicAdd(&ws.count[round + 1], n_full) : 0;
             s_base[1] = n_energy ? atomicAdd(&ws.count[SPLIT_COUNT_STRIDE + round + 1], n_energy) : 0;
+            s_base[2] = n_side ? atomicAdd(&ws.count[SPLIT_SIDE_COUNT], n_side) : 0;
         }
         __syncthreads();
         if (lane == 0 && append_kind >= 0) {
             int rank = 0;
             for (int w = 0; w < wave; ++w) rank += s_kind[w] == append_kind ? 1 : 0;
-            if (append_kind == 1) ws.list[(round + 1) & 1][ws.cap - 1 - (s_base[1] + rank)] = pair;
+            if (append_kind == 2) ws.side_list[s_base[2] + rank] = pair;
+            else if (append_kind == 1) ws.list[(round + 1) & 1][ws.cap - 1 - (s_base[1] + rank)] = pair;
             else ws.list[(round + 1) & 1][s_base[0] + rank] = pair;
         }
         __syncthreads();
     }
 }
 
+// The pairs the side lane has brought to level 0 enter round `round` as pairs due a full evaluation (a level's init).
+__global__ __launch_bounds__(256) void lm_split_merge_kernel(LmSplitWs ws, int round) {
+    const int n = ws.count[SPLIT_JOIN_COUNT];
+    for (int i = threadIdx.x; i < n; i += 256) ws.list[round & 1][atomicAdd(&ws.count[round], 1)] = ws.join_list[i];
+}
+void launch_lm_split_merge(LmSplitWs ws, int round, hipStream_t s) { hipLaunchKernelGGL(lm_split_merge_kernel, dim3(1), dim3(256), 0, s, ws, round); }
 void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s) {
     if (grid >= 1024 && !late)
         hipLaunchKernelGGL(lm_split_step_kernel<8>, dim3((grid + 7) / 8), dim3(512), 0, s, g, ws, out_stats, round, late, next_late);
@@ -1973,7 +2005,8 @@ void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stat
         hipLaunchKernelGGL(lm_split_step_kernel<1>, dim3(grid), dim3(64), 0, s, g, ws, out_stats, round, late, next_late);
 }
 #else
-// host-side launcher of the (arithmetic-independent) step kernel, defined in the exact object
+// host-side launchers of the (arithmetic-independent) step and merge kernels, defined in the exact object
+void launch_lm_split_merge(LmSplitWs ws, int round, hipStream_t s);
 void launch_lm_split_step(const Geom& g, LmSplitWs ws, vors_pair_stats* out_stats, int round, int late, int next_late, int grid, hipStream_t s);
 #endif
 
@@ -2064,7 +2097,8 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
     // the rare pairs still iterating after the last round)
     split.n_split = std::max(1, std::min(split.n_split, g.L));
     split.rounds = std::max(1, std::min(split.rounds, VORS_SPLIT_MAX_ROUNDS));
-    (void)hipMemsetAsync(split.count, 0, 2 * (VORS_SPLIT_MAX_ROUNDS + 2) * sizeof(int), s);
+    (void)hipMemsetAsync(split.count, 0, SPLIT_COUNT_INTS * sizeof(int), s);
+    const int join_round = split.side_round >= 0 ? std::min(split.side_round + 3, split.rounds) : -1;
     launch_lm_track_mode(VORS_LM_MARGS, 1, split, s);
     const int base_chunks = std::max(1, split.chunks / 4);
     for (int r = 0; r < split.rounds; ++r) {
@@ -2074,7 +2108,12 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
         static const int late_env = getenv("VORS_LM_LATE_FROM") ? atoi(getenv("VORS_LM_LATE_FROM")) : -1;  // (development knob)
         const int late_from = late_env >= 0 ? late_env : 2 * split.n_split + 2;
         const int late = r >= late_from, next_late = r + 1 >= late_from;
-        split.chunks0 = late ? split.chunks : base_chunks;
+        if (r == join_round) {  // the side lane's pairs come back (it has had two long rounds to finish: no wait in practice)
+            (void)hipStreamWaitEvent(s, split.ev_join, 0);
+            launch_lm_split_merge(split, r, s);
+        }
+        static const int late_chunks_env = getenv("VORS_LM_LATE_CHUNKS") ? atoi(getenv("VORS_LM_LATE_CHUNKS")) : 0;  // (development knob)
+        split.chunks0 = late ? (late_chunks_env > 0 ? std::min(late_chunks_env, split.chunks) : split.chunks) : base_chunks;
         const int full = n_pairs * split.chunks0;
         const int shrink = r < 2 * split.n_split ? 1 : (late ? 16 : 2);
         const int grid = std::max(std::min(full, 256), full / shrink);
@@ -2092,6 +2131,17 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
         }
 #undef VORS_SPLIT_KARGS
         launch_lm_split_step(g, split, out_stats, r, late, next_late, std::max(1, n_pairs / shrink), s);
+        if (r == split.side_round) {  // fork: the pairs still above level 0 finish those levels on the side stream, one workgroup each
+            (void)hipEventRecord(split.ev_fork, s);
+            (void)hipStreamWaitEvent(split.side_stream, split.ev_fork, 0);
+            launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, n_pairs, 1024, 4, split,
+                                 split.side_stream);
+            (void)hipEventRecord(split.ev_join, split.side_stream);
+        }
+    }
+    if (join_round == split.rounds) {
+        (void)hipStreamWaitEvent(s, split.ev_join, 0);
+        launch_lm_split_merge(split, split.rounds, s);
     }
     // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
     launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
