@@ -801,7 +801,7 @@ struct vors_tracker {
     DevBuf gray, depth, tmp8, tmp16;   // the frame on the device (row-major); tmp*: column-major uploads before the transpose
     PinnedBuf h_gray, h_depth, h_out;  // staging: frame in; pose7 + status + keyframe index + vors_pair_stats out
     hipStream_t s_main = nullptr, s_copy = nullptr;
-    hipEvent_t ev_depth = nullptr, ev_frame_done = nullptr;
+    hipEvent_t ev_depth = nullptr, ev_frame_done = nullptr, ev_result = nullptr;
     // State of inverse_compositional.rs:52-60 as the host reports it
     double keyframe_depth_timestamp = 0, keyframe_img_timestamp = 0;
     Iso keyframe_pose = iso_identity();
@@ -813,6 +813,7 @@ struct vors_tracker {
         vors_trackers_destroy(seq);
         if (ev_depth) (void)hipEventDestroy(ev_depth);
         if (ev_frame_done) (void)hipEventDestroy(ev_frame_done);
+        if (ev_result) (void)hipEventDestroy(ev_result);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_copy) (void)hipStreamDestroy(s_copy);
     }
@@ -829,7 +830,7 @@ struct TrackerOut {  // layout of vors_tracker::h_out
 // and the LM stage of the frame: only the promotion at the end of the frame reads it.
 static vors_status tracker_upload_gray(vors_tracker* t, const uint8_t* gray) {
     const size_t S = (size_t)t->rows * t->cols;
-    std::memcpy(t->h_gray.p, gray, S);
+    std::memcpy(t->h_gray.p, gray, S);  // (the previous upload has completed: its results were waited for)
     if (t->layout == VORS_ROW_MAJOR) {
         HIP_TRY(hipMemcpyAsync(t->gray.p, t->h_gray.p, S, hipMemcpyHostToDevice, t->s_main));
     } else {
@@ -840,7 +841,8 @@ static vors_status tracker_upload_gray(vors_tracker* t, const uint8_t* gray) {
 }
 static vors_status tracker_upload_depth(vors_tracker* t, const uint16_t* depth) {
     const size_t S = (size_t)t->rows * t->cols;
-    std::memcpy(t->h_depth.p, depth, S * 2);  // (the previous frame has been synchronised: nobody reads the staging buffer any more)
+    HIP_TRY(hipEventSynchronize(t->ev_depth));  // (track() returns once the RESULTS are back: the previous depth upload may still be reading the staging buffer)
+    std::memcpy(t->h_depth.p, depth, S * 2);
     // the previous frame's promotion may still read t->depth: the copy stream first waits for the end of the previous frame
     HIP_TRY(hipStreamWaitEvent(t->s_copy, t->ev_frame_done, 0));
     if (t->layout == VORS_ROW_MAJOR) {
@@ -893,6 +895,7 @@ vors_status vors_tracker_create(const vors_config* cfg, double depth_time, const
     HIP_TRY(hipStreamCreateWithFlags(&t->s_copy, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_depth, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_frame_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_result, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
     if ((st = tracker_upload(t, gray, depth)) != VORS_OK) return st;
     HIP_TRY(hipStreamWaitEvent(t->s_main, t->ev_depth, 0));
@@ -920,22 +923,25 @@ vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_
     // Tracker::track (inverse_compositional.rs:170-240) incl. the keyframe switch, all on the device. Order on the host: grey image up,
     // pyramid + LM + keyframe test enqueued, THEN the depth map staged and sent on the copy stream (under the LM stage), then the
     // promotion, which waits for it.
-    vors_status st = tracker_upload_gray(t, gray);
-    if (st != VORS_OK) return st;
-    if ((st = trackers_track_lm(t->seq, t->gray.as<uint8_t>(), t->s_main)) != VORS_OK) return st;
-    if ((st = tracker_upload_depth(t, depth)) != VORS_OK) return st;
-    if ((st = trackers_promote(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main)) != VORS_OK) return st;
-    HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
+    // ... and the host returns as soon as the RESULTS are back (a packed record the device stores into pinned host memory), while the
+    // promotion of a switching frame still runs: the next call is ordered behind it on the stream.
     const float* d_pose = nullptr;
     const int32_t *d_status = nullptr, *d_kf = nullptr;
     const vors_pair_stats* d_stats = nullptr;
     (void)vors_trackers_state(t->seq, &d_pose, nullptr, &d_status, &d_kf, &d_stats);
     TrackerOut* o = t->h_out.as<TrackerOut>();
-    HIP_TRY(hipMemcpyAsync(o->pose, d_pose, sizeof(o->pose), hipMemcpyDeviceToHost, t->s_main));
-    HIP_TRY(hipMemcpyAsync(&o->status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, t->s_main));
-    HIP_TRY(hipMemcpyAsync(&o->kf_index, d_kf, sizeof(int32_t), hipMemcpyDeviceToHost, t->s_main));
-    HIP_TRY(hipMemcpyAsync(&o->stats, d_stats, sizeof(vors_pair_stats), hipMemcpyDeviceToHost, t->s_main));
-    HIP_TRY(hipStreamSynchronize(t->s_main));
+    vors_status st = VORS_OK;
+    // (A HIP graph of this per-frame sequence — it has no per-frame argument any more: the frame index lives on the device — was built and
+    // measured in round 4: 0.172 vs 0.174 ms per frame. The launches are enqueued ahead of the device anyway; what the frame waits for is
+    // the LM kernel's chain of ~35 dependent evaluations. Not kept.)
+    if ((st = tracker_upload_gray(t, gray)) != VORS_OK) return st;
+    if ((st = trackers_track_lm(t->seq, t->gray.as<uint8_t>(), t->s_main)) != VORS_OK) return st;
+    launch_tracker_pack_out(d_pose, d_status, d_kf, d_stats, o, t->s_main);
+    HIP_TRY(hipEventRecord(t->ev_result, t->s_main));
+    if ((st = tracker_upload_depth(t, depth)) != VORS_OK) return st;
+    if ((st = trackers_promote(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main)) != VORS_OK) return st;
+    HIP_TRY(hipEventRecord(t->ev_frame_done, t->s_main));
+    HIP_TRY(hipEventSynchronize(t->ev_result));
     t->last = o->stats;
     t->has_last = true;
     // inverse_compositional.rs:203-208
@@ -1121,7 +1127,7 @@ struct vors_trackers {
     int n_seq = 0;
     int frame_index = 0;  // index of the last frame submitted (0 = the init frame)
     bool initialised = false;
-    DevBuf cur_poses, kf_poses, out_poses, status, stats, kf_frame, promo_list, promo_count;
+    DevBuf cur_poses, kf_poses, out_poses, status, stats, kf_frame, promo_list, promo_count, frame_counter;
     DevBuf own_gray, own_depth;  // dense mode: the keyframes' level 0 and depth maps (re-read by every evaluation) live in the handle
     ~vors_trackers() { vors_batch_destroy(batch); }
 };
@@ -1160,6 +1166,7 @@ vors_status vors_trackers_create_on(int device, const vors_config* cfg, int n_se
     HIP_TRY(t->kf_frame.alloc(n * sizeof(int32_t)));
     HIP_TRY(t->promo_list.alloc(n * sizeof(int)));
     HIP_TRY(t->promo_count.alloc(sizeof(int)));
+    HIP_TRY(t->frame_counter.alloc(sizeof(int)));
     if (b->g.mode == VORS_CANDIDATES_DENSE) {
         HIP_TRY(t->own_gray.alloc(n * S));
         HIP_TRY(t->own_depth.alloc(n * S * 2));
@@ -1206,6 +1213,7 @@ vors_status vors_trackers_init(vors_trackers* t, const uint8_t* d_gray, const ui
     launch_identity_poses(t->cur_poses.as<float>(), t->kf_poses.as<float>(), t->n_seq, s);  // (on the device: init only enqueues work, like track)
     HIP_TRY(hipMemsetAsync(t->kf_frame.p, 0, n * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(t->status.p, 0, n * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(t->frame_counter.p, 0, sizeof(int), s));
     HIP_TRY(hipGetLastError());
     t->frame_index = 0;
     t->initialised = true;
@@ -1233,7 +1241,7 @@ static vors_status trackers_track_lm(vors_trackers* t, const uint8_t* d_gray, hi
                              t->stats.as<vors_pair_stats>(), s);
     if (st != VORS_OK) return st;
     // :203-208 and :224-239 on the device: poses forward, promotion list
-    launch_trackers_advance(n, t->frame_index, t->out_poses.as<float>(), t->stats.as<vors_pair_stats>(), t->cur_poses.as<float>(),
+    launch_trackers_advance(n, t->frame_counter.as<int>(), t->out_poses.as<float>(), t->stats.as<vors_pair_stats>(), t->cur_poses.as<float>(),
                             t->kf_poses.as<float>(), t->kf_frame.as<int32_t>(), t->promo_list.as<int>(), t->promo_count.as<int>(), s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;

@@ -232,7 +232,9 @@ void launch_synth_pairs(uint64_t seed0, int n_pairs, int rows, int cols, const d
 // Sequence tooling + the device side of vors_trackers_* (kernels.hip).
 void launch_synth_frames(const void* d_frames /* {u64 seed, u64 salt, f64 xi[6]} x n */, int n_frames, int rows, int cols, const double cam5[5],
                          int invalid_percent, uint8_t* gray, uint16_t* depth, hipStream_t s);
-void launch_trackers_advance(int n_seq, int frame_index, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
+void launch_tracker_pack_out(const float* pose7, const int32_t* status, const int32_t* kf_frame, const vors_pair_stats* stats, void* out,
+                             hipStream_t s);
+void launch_trackers_advance(int n_seq, int* frame_counter, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
                              float* kf_poses7, int32_t* kf_frame, int* promo_list, int* promo_count, hipStream_t s);
 void launch_identity_poses(float* a, float* b, int n, hipStream_t s);  // two pose tables -> identity (inverse_compositional.rs:86-99)
 void launch_promote_copy(const Geom& g, const void* src, size_t src_stride, void* dst, size_t dst_stride, size_t bytes, int n_pairs,

@@ -963,14 +963,18 @@ void launch_synth_frames(const void* d_frames, int n_frames, int rows, int cols,
 // whose optimizer failed, :206-208); a sequence whose optical flow reached the threshold (:224) takes the current frame as its keyframe:
 // keyframe_pose <- current_frame_pose (:238), and it is appended to the promotion list that the masked keyframe launches read.
 // One workgroup; the list comes out in sequence order (wave ballots + a running base), so every launch that follows is deterministic.
-__global__ __launch_bounds__(256) void trackers_advance_kernel(int n_seq, int frame_index, const float* __restrict__ out_poses7,
+// The frame index lives on the device (`frame_counter`, incremented here) so that the launch carries no per-frame argument: the
+// single-sequence tracker replays its per-frame launch sequence from a HIP graph.
+__global__ __launch_bounds__(256) void trackers_advance_kernel(int n_seq, int* __restrict__ frame_counter, const float* __restrict__ out_poses7,
                                                                const vors_pair_stats* __restrict__ stats, float* __restrict__ cur_poses7,
                                                                float* __restrict__ kf_poses7, int32_t* __restrict__ kf_frame,
                                                                int* __restrict__ promo_list, int* __restrict__ promo_count) {
     __shared__ int s_wave[4];
     __shared__ int s_base;
+    const int frame_index = *frame_counter + 1;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
+    if (threadIdx.x == 0) *frame_counter = frame_index;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s0 = 0; s0 < n_seq; s0 += 256) {
         const int s = s0 + (int)threadIdx.x;
@@ -997,10 +1001,27 @@ __global__ __launch_bounds__(256) void trackers_advance_kernel(int n_seq, int fr
     }
     if (threadIdx.x == 0) *promo_count = s_base;
 }
-void launch_trackers_advance(int n_seq, int frame_index, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
+void launch_trackers_advance(int n_seq, int* frame_counter, const float* out_poses7, const vors_pair_stats* stats, float* cur_poses7,
                              float* kf_poses7, int32_t* kf_frame, int* promo_list, int* promo_count, hipStream_t s) {
-    hipLaunchKernelGGL(trackers_advance_kernel, dim3(1), dim3(256), 0, s, n_seq, frame_index, out_poses7, stats, cur_poses7, kf_poses7, kf_frame,
+    hipLaunchKernelGGL(trackers_advance_kernel, dim3(1), dim3(256), 0, s, n_seq, frame_counter, out_poses7, stats, cur_poses7, kf_poses7, kf_frame,
                        promo_list, promo_count);
+}
+// Results of sequence 0 of a lock-step handle as ONE packed record (pose7, status, keyframe index, vors_pair_stats; capi.cpp TrackerOut),
+// stored by the device straight into the caller's pinned host memory: the single-sequence tracker reads its frame back without a copy call.
+__global__ __launch_bounds__(64) void tracker_pack_out_kernel(const float* __restrict__ pose7, const int32_t* __restrict__ status,
+                                                              const int32_t* __restrict__ kf_frame, const vors_pair_stats* __restrict__ stats,
+                                                              uint32_t* __restrict__ out) {
+    const int t = threadIdx.x;
+    constexpr int NS = (int)(sizeof(vors_pair_stats) / 4);
+    if (t < 7) out[t] = __float_as_uint(pose7[t]);
+    if (t == 7) out[7] = (uint32_t)status[0];
+    if (t == 8) out[8] = (uint32_t)kf_frame[0];
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(stats);
+    for (int i = t; i < NS; i += 64) out[9 + i] = sp[i];
+}
+void launch_tracker_pack_out(const float* pose7, const int32_t* status, const int32_t* kf_frame, const vors_pair_stats* stats, void* out,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(tracker_pack_out_kernel, dim3(1), dim3(64), 0, s, pose7, status, kf_frame, stats, static_cast<uint32_t*>(out));
 }
 // Dense mode keeps its keyframes (level 0, depth map, upper pyramid levels) in the handle: the promoted sequences copy theirs from the
 // current frame (the reference MOVES the current pyramid into the keyframe, inverse_compositional.rs:230-235). 16 bytes per thread.
