@@ -36,11 +36,14 @@ np.savez(out, **res)
 """
 
 
-def run(tmp_path, tag, planes, rows, cols, L, scan=False, threads=None):
+def run(tmp_path, tag, planes, rows, cols, L, scan=False, threads=None, sort=None):
     out = str(tmp_path / f"{tag}.npz")
     env = dict(os.environ)
     env["VORS_DSO_PLANES"] = "1" if planes else "0"
     env["VORS_DSO_SCAN"] = "1" if scan else "0"
+    env.pop("VORS_DSO_SORT", None)
+    if sort:
+        env["VORS_DSO_SORT"] = sort
     if threads:
         env["VORS_DSO_ROUNDS_THREADS"], env["VORS_DSO_RECORDS_THREADS"] = str(threads[0]), str(threads[1])
     subprocess.run([sys.executable, "-c", DUMP.format(root=ROOT, rows=rows, cols=cols, L=L, out=out)], check=True, env=env, timeout=300)
@@ -79,5 +82,17 @@ def test_threads_per_pair_of_the_selector_and_records_kernels_do_not_change_the_
     same candidates, same values, same order, hence the same poses bit for bit."""
     a = run(tmp_path, "t1024", False, rows, cols, L, threads=(1024, 1024))
     b = run(tmp_path, "t512", False, rows, cols, L, threads=(512, 512))
+    for key in a.files:
+        assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key
+
+
+@pytest.mark.parametrize("rows,cols,L,threads", [(480, 640, 6, (512, 512)), (480, 640, 6, (1024, 1024)), (121, 163, 4, None), (960, 1280, 7, None), (64, 96, 2, None)])
+def test_bucket_sort_of_the_pick_list_equals_the_bitonic_network(tmp_path, rows, cols, L, threads):
+    """Round 4: the records kernel orders a pair's picks (distinct Morton codes) with a two-step bucket sort in LDS — a counter per image tile,
+    then an element's place among its few tile mates — instead of round 3's 66-stage bitonic network (VORS_DSO_SORT=bitonic keeps it).
+    Same order, hence the same lists, values and poses bit for bit; 1280x960 has 22-bit codes (64x64-pixel buckets), 64x96 overflows into
+    groups of bands."""
+    a = run(tmp_path, "bucket", False, rows, cols, L, threads=threads)
+    b = run(tmp_path, "bitonic", False, rows, cols, L, threads=threads, sort="bitonic")
     for key in a.files:
         assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key

@@ -1,6 +1,6 @@
 """Development aid (run through gpurun): stage times (HIP events on the stream) of a step for several batch sizes and the three candidate
 modes, and the ratio of the step times — BASELINE config 4 as written is 4096 pairs over 8 GPUs, i.e. 512 pairs per GPU: the 512-pair
-step must take at most 1/6 of the 4096-pair step for the >= 6x target.    usage: python tools/stage_times.py [arith] [batches...]"""
+step must take at most 1/6 of the 4096-pair step for the >= 6x target.    usage: [MODES=c2f,dso] python tools/stage_times.py [arith] [batches...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
@@ -12,6 +12,8 @@ batches = [int(x) for x in sys.argv[2:]] or [512, 4096]
 rows, cols, L = 480, 640, 6
 intr = V.scaled_intrinsics(rows, cols)
 for mode, name in ((0, "c2f"), (2, "dso"), (1, "dense")):
+    if os.environ.get("MODES") and name not in os.environ["MODES"].split(","):
+        continue
     res = {}
     for n in batches:
         kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED0000 | ((1 << 63) if mode == 2 else 0), n, rows, cols, intr)

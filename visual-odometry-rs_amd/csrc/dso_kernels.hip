@@ -949,53 +949,129 @@ __device__ __forceinline__ void sparse_scan(const SparseScan& q, int p0, int p1,
 template <int T>
 __device__ __forceinline__ void sparse_flush(const Geom& g, const uint8_t* kf0, const uint8_t* kfu, int pair, const uint64_t* gsort, int n0,
                                              uint64_t* a, bool copy_in, uint32_t* key, int cap_set, const Records& rec, int* s_wave, int* s_out,
-                                             uint32_t* s_prev) {
+                                             uint32_t* s_prev, bool bitonic) {
     const int tid = threadIdx.x;
-    int P = 2;
-    while (P < n0) P <<= 1;
-    if (copy_in)
-        for (int i = tid; i < P; i += T) a[i] = i < n0 ? gsort[i] : ~0ull;
-    else
-        for (int i = n0 + tid; i < P; i += T) a[i] = ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += T) {
-                const int q = i ^ j;
-                if (q > i) {
-                    const uint64_t x = a[i], y = a[q];
-                    if ((x > y) == ((i & k) == 0)) {
-                        a[i] = y;
-                        a[q] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
     // One set of (key, inverse depth, weight) arrays, rewritten in place level by level: a pass reads its inputs into registers, meets
     // at a barrier, then writes (the outputs of a level land at or below inputs already consumed).
     float* dd = reinterpret_cast<float*>(key + cap_set);
     float* vv = reinterpret_cast<float*>(key + 2 * cap_set);
-    if (copy_in) {  // LDS form: the arrays take the place of the sorted words (n0 <= 4096: four words per thread through registers)
-        uint64_t c[SPARSE_LDS_N / T];
-#pragma unroll
-        for (int q = 0; q < SPARSE_LDS_N / T; ++q) c[q] = tid + T * q < n0 ? a[tid + T * q] : 0ull;
+    if (copy_in && !bitonic) {
+        // LDS form, round 4: a two-step BUCKET sort instead of the bitonic network (66 dependent compare-exchange stages with an LDS
+        // round trip and a barrier each: 0.45 of the kernel's 0.60 ms per 4096 pairs). The keys are distinct pixel positions, so:
+        //  1. bucket = the high bits of the Morton code (at most 1024 buckets = square tiles of the image in Morton order): a counter
+        //     per bucket, an element's slot in its bucket from the atomic's return value (any order);
+        //  2. exclusive scan of the counters, elements scattered to bucket start + slot;
+        //  3. an element's final place = bucket start + the number of bucket mates with a smaller word (a DSO pick list holds at most one
+        //     pick per 4x4 block and a few from the recursive rounds: a handful of mates; any mask works, a dense one just loops longer).
+        // Five barriers; the (key, inverse depth, weight) arrays are written straight from the registers.
+        constexpr int Q = SPARSE_LDS_N / T, BINS = 1024, PER = BINS / T > 0 ? BINS / T : 1;
+        static_assert(BINS % T == 0 || T > BINS, "bins per thread");
+        uint32_t* hist = key + 2 * cap_set;  // (the weights' place: free until the arrays are written)
+        const uint32_t code_max = morton_part((uint32_t)(g.lv[0].rows - 1)) | (morton_part((uint32_t)(g.lv[0].cols - 1)) << 1);
+        const int nbits = 32 - __builtin_clz(code_max | 1u), shift = 16 + max(0, nbits - 10);
+        for (int i = tid; i < BINS; i += T) hist[i] = 0;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < SPARSE_LDS_N / T; ++q) {
-            const int i = tid + T * q;
-            if (i < n0) {
-                key[i] = (uint32_t)(c[q] >> 16);
-                dd[i] = g.depth_scale / (float)(uint32_t)(c[q] & 0xffffu);  // from_depth, inverse_depth.rs:24-29
+        for (int q = 0; q < Q; ++q)
+            if (tid + T * q < n0) atomicAdd(&hist[(uint32_t)(gsort[tid + T * q] >> shift)], 1u);
+        __syncthreads();
+        {
+            uint32_t c[PER], sum = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                c[j] = tid * PER + j < BINS ? hist[tid * PER + j] : 0;
+                sum += c[j];
+            }
+            const int lane = tid & 63, wave = tid >> 6;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_wave[wave] = (int)incl;
+            __syncthreads();
+            uint32_t before = incl - sum;
+#pragma unroll
+            for (int k = 0; k < T / 64; ++k) before += k < wave ? (uint32_t)s_wave[k] : 0u;
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (tid * PER + j < BINS) {
+                    hist[tid * PER + j] = before;  // start of the bucket; the scatter below moves it to the bucket's end
+                    before += c[j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (tid + T * q < n0) {  // (the words again, from L2: cheaper than 16 registers held across the scan)
+                const uint64_t w = gsort[tid + T * q];
+                a[atomicAdd(&hist[(uint32_t)(w >> shift)], 1u)] = w;
+            }
+        __syncthreads();
+        uint64_t wp[Q];  // word | final place << 52 (a word has at most 48 bits: 32 of Morton code, 16 of depth)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (tid + T * q < n0) {
+                const uint64_t w = a[tid + T * q];
+                const uint32_t bin = (uint32_t)(w >> shift);
+                const int b0 = bin ? (int)hist[bin - 1] : 0, b1 = (int)hist[bin];
+                int r = b0;
+                for (int j = b0; j < b1; ++j) r += a[j] < w ? 1 : 0;
+                wp[q] = w | ((uint64_t)r << 52);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (tid + T * q < n0) {
+                const int place = (int)(wp[q] >> 52);
+                key[place] = (uint32_t)(wp[q] >> 16);
+                dd[place] = g.depth_scale / (float)(uint32_t)(wp[q] & 0xffffu);  // from_depth, inverse_depth.rs:24-29
+                vv[place] = g.idepth_variance;
+            }
+    } else {
+        int P = 2;
+        while (P < n0) P <<= 1;
+        if (copy_in)
+            for (int i = tid; i < P; i += T) a[i] = i < n0 ? gsort[i] : ~0ull;
+        else
+            for (int i = n0 + tid; i < P; i += T) a[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += T) {
+                    const int q = i ^ j;
+                    if (q > i) {
+                        const uint64_t x = a[i], y = a[q];
+                        if ((x > y) == ((i & k) == 0)) {
+                            a[i] = y;
+                            a[q] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        if (copy_in) {  // LDS form: the arrays take the place of the sorted words (n0 <= 4096: four words per thread through registers)
+            uint64_t c[SPARSE_LDS_N / T];
+#pragma unroll
+            for (int q = 0; q < SPARSE_LDS_N / T; ++q) c[q] = tid + T * q < n0 ? a[tid + T * q] : 0ull;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < SPARSE_LDS_N / T; ++q) {
+                const int i = tid + T * q;
+                if (i < n0) {
+                    key[i] = (uint32_t)(c[q] >> 16);
+                    dd[i] = g.depth_scale / (float)(uint32_t)(c[q] & 0xffffu);  // from_depth, inverse_depth.rs:24-29
+                    vv[i] = g.idepth_variance;
+                }
+            }
+        } else {
+            for (int i = tid; i < n0; i += T) {
+                const uint64_t c = a[i];
+                key[i] = (uint32_t)(c >> 16);
+                dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);
                 vv[i] = g.idepth_variance;
             }
-        }
-    } else {
-        for (int i = tid; i < n0; i += T) {
-            const uint64_t c = a[i];
-            key[i] = (uint32_t)(c >> 16);
-            dd[i] = g.depth_scale / (float)(uint32_t)(c & 0xffffu);
-            vv[i] = g.idepth_variance;
         }
     }
     __syncthreads();
@@ -1181,9 +1257,9 @@ __global__ __launch_bounds__(256) void mask_sparse_scan_kernel(Geom g, const uin
 }
 #undef SCAN_T0
 template <int T>
-__global__ __launch_bounds__(T) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 512 ? 6 : 4))) void mask_sparse_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                     const uint16_t* __restrict__ depth, uint8_t* __restrict__ mask, DsoWs ws,
-                                                                    int from_stamps, PixelPlanes pp, Records rec, int cap_n) {
+                                                                    int from_stamps, PixelPlanes pp, Records rec, int cap_n, int bitonic) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_set[3 * SPARSE_LDS_N];  // 48 KB: the sort words first (32 KB), then the three arrays in their place
     uint64_t* lds_sort = reinterpret_cast<uint64_t*>(lds_set);
     __shared__ int s_n, s_wave[16], s_out[VORS_MAX_LEVELS];
@@ -1241,9 +1317,9 @@ __global__ __launch_bounds__(T) void mask_sparse_records_kernel(Geom g, const ui
         }
         if (n0 == 0) continue;
         if (n0 <= SPARSE_LDS_N)
-            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, lds_sort, true, lds_set, SPARSE_LDS_N, rec, s_wave, s_out, &s_prev);
+            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, lds_sort, true, lds_set, SPARSE_LDS_N, rec, s_wave, s_out, &s_prev, bitonic != 0);
         else
-            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, gsort, false, gset, cap_n, rec, s_wave, s_out, &s_prev);
+            sparse_flush<T>(g, kf0, kfu, pair, gsort, n0, gsort, false, gset, cap_n, rec, s_wave, s_out, &s_prev, true);
     }
     __syncthreads();
     if (tid < g.L) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + tid] = s_out[tid];
@@ -1276,10 +1352,13 @@ void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs
         const char* e = getenv("VORS_DSO_RECORDS_THREADS");
         const int forced = e ? atoi(e) : 0;
         const int rt = (forced == 512 || forced == 1024) ? forced : (n_pairs >= 512 ? 512 : 1024);
+        // VORS_DSO_SORT=bitonic: round 3's sort network in the LDS form instead of the bucket sort (same lists; A/B and tests; read per launch)
+        const char* so = getenv("VORS_DSO_SORT");
+        const int bitonic = (so && so[0] == 'b') ? 1 : 0;
         if (rt == 512)
-            hipLaunchKernelGGL(mask_sparse_records_kernel<512>, dim3(n_pairs), dim3(512), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
+            hipLaunchKernelGGL(mask_sparse_records_kernel<512>, dim3(n_pairs), dim3(512), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n, bitonic);
         else
-            hipLaunchKernelGGL(mask_sparse_records_kernel<1024>, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n);
+            hipLaunchKernelGGL(mask_sparse_records_kernel<1024>, dim3(n_pairs), dim3(1024), 0, s, g, kf.level0, kf.upper, depth, no_mask, ws, 1, pp, rec, cap_n, bitonic);
         return;
     }
     launch_dso_selection(g, kf, ws, n_pairs, s);
