@@ -473,38 +473,48 @@ def reference_parity(V, args, device, seed0, sizes):
     from oracle import oracle as O
     out = {}
     ncores = os.cpu_count() or 1
+    def one(mode, a, n, reps):
+        w = Workload(V, a, mode, device, seed0, pairs=n)
+        w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        kg, kd, cg = host_pairs(w, n)
+        ref = O.track_pairs(O.make_config(a.levels, w.intr, candidates_mode=w.mode_id, huber_delta=a.huber), kg, kd, cg, n_threads=min(ncores, n))
+        poses = w.poses.cpu().numpy()
+        st = V.decode_stats(w.stats)
+        L = a.levels
+        same_pose = (poses.view(np.uint32) == ref["poses"].view(np.uint32)).all(axis=1)
+        same_model = (np.ascontiguousarray(st["lm_model"]).view(np.uint32) == ref["models"].view(np.uint32)).all(axis=1)
+        same_iter = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1)
+        same_flow = np.ascontiguousarray(st["optical_flow"]).view(np.uint32) == ref["flow"].view(np.uint32)
+        err = np.abs(poses - ref["poses"]).max(axis=1)
+        res = {"sample_pairs": int(n), "n_poses_bit_identical": int(same_pose.sum()), "n_lm_models_bit_identical": int(same_model.sum()),
+               "n_iteration_counts_equal_at_every_level": int(same_iter.sum()), "n_optical_flow_bit_identical": int(same_flow.sum()),
+               "branch_flip_rate_gpu_vs_oracle": float((~same_iter).mean()), "n_beyond_tol": int((err > 1e-4).sum()),
+               "max_pose_diff_gpu_vs_oracle": float(err.max(initial=0.0)),
+               "status_equal": bool((w.status.cpu().numpy() == ref["status"]).all()),
+               "frame_pairs_per_s": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+        del w
+        return res
+
     for mode in ("c2f", "dso", "dense"):
         n = min(sizes[mode], args.pairs)
         if n <= 0:
             continue
         a = copy.copy(args)
         a.arith = "reference"
-        w = Workload(V, a, mode, device, seed0, pairs=n)
-        w.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 3 if mode != "dense" else 1
-        for _ in range(reps):
-            w.step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        kg, kd, cg = host_pairs(w, n)
-        ref = O.track_pairs(O.make_config(args.levels, w.intr, candidates_mode=w.mode_id, huber_delta=args.huber), kg, kd, cg, n_threads=min(ncores, n))
-        poses = w.poses.cpu().numpy()
-        st = V.decode_stats(w.stats)
-        L = args.levels
-        same_pose = (poses.view(np.uint32) == ref["poses"].view(np.uint32)).all(axis=1)
-        same_model = (np.ascontiguousarray(st["lm_model"]).view(np.uint32) == ref["models"].view(np.uint32)).all(axis=1)
-        same_iter = (st["nb_iter"][:, :L] == ref["nb_iter"]).all(axis=1)
-        same_flow = np.ascontiguousarray(st["optical_flow"]).view(np.uint32) == ref["flow"].view(np.uint32)
-        err = np.abs(poses - ref["poses"]).max(axis=1)
-        out[mode] = {"sample_pairs": int(n), "n_poses_bit_identical": int(same_pose.sum()), "n_lm_models_bit_identical": int(same_model.sum()),
-                     "n_iteration_counts_equal_at_every_level": int(same_iter.sum()), "n_optical_flow_bit_identical": int(same_flow.sum()),
-                     "branch_flip_rate_gpu_vs_oracle": float((~same_iter).mean()), "n_beyond_tol": int((err > 1e-4).sum()),
-                     "max_pose_diff_gpu_vs_oracle": float(err.max(initial=0.0)),
-                     "status_equal": bool((w.status.cpu().numpy() == ref["status"]).all()),
-                     "frame_pairs_per_s": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
-        del w
+        out[mode] = one(mode, a, n, 3 if mode != "dense" else 1)
+    if (args.rows, args.cols, args.levels) == (480, 640, 6) and min(sizes["dense"], args.pairs) >= 32:
+        # BASELINE config 5's shape (1280x960, 7 levels, Huber 10 — the extension, defined by the oracle) and config 3's candidates at that
+        # shape: a small sample each, the same equality of bits
+        a = copy.copy(args)
+        a.arith, a.rows, a.cols, a.levels, a.huber = "reference", 960, 1280, 7, 10.0
+        out["config5_shape_dense_huber10"] = one("dense", a, 32, 1)
+        out["config5_shape_c2f_huber10"] = one("c2f", a, 64, 1)
     out["note"] = ("arithmetic = reference: EXACT's per-point arithmetic + the reference's sequential f32 sums in extract_z's column-major order "
                    "(lm_reference.hip); compared with the oracle bit for bit")
     return out
