@@ -567,7 +567,7 @@ void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* im
 #define SORT_WORDS 4096  // 131,072 keys per segment: 16 KB of bits + 16 KB of word prefixes
 #define SORT_BLOCK 512
 #define SORT_U 8          // independent loads in flight per thread (a pass is a chain of global round trips otherwise)
-__global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Records rec) {
+__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void sort_colmajor_kernel(Geom g, Records rec) {
     __shared__ uint32_t bits[SORT_WORDS];
     __shared__ int wpre[SORT_WORDS];  // set bits in the words before this one (within the segment)
     __shared__ int wsum[SORT_BLOCK / 64];
@@ -584,6 +584,67 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_colmajor_kernel(Geom g, Recor
     SlimRec* T = rec.sort_tmp + lvl0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
+    if (n <= SORT_BLOCK * SORT_U) {
+        // Round 4: a list of at most 4096 records (every level of the reference's shapes) stays in REGISTERS — 8 records per thread — while the
+        // segments of the key space go by; each record learns its rank in its segment, and the list is written back IN PLACE at the end. One read
+        // and one write of the list instead of a read per segment and pass, a scratch copy and a copy back: 3.5 GB of traffic per 4096
+        // coarse-to-fine pairs became 1 GB.
+        SlimRec r[SORT_U];
+        int rank[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; ++u) {
+            const int i = (int)threadIdx.x + u * SORT_BLOCK;
+            r[u] = i < n ? S[i] : SlimRec{0xffffffffu, 0.f, 0u};
+            rank[u] = -1;
+        }
+        for (unsigned seg0 = 0; seg0 < nkeys; seg0 += SORT_WORDS * 32u) {
+            const unsigned seg_keys = min(nkeys - seg0, SORT_WORDS * 32u);
+            const int words = (int)((seg_keys + 31u) >> 5);
+            const int wpt = (words + SORT_BLOCK - 1) / SORT_BLOCK;
+            for (int w = threadIdx.x; w < words; w += SORT_BLOCK) bits[w] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SORT_U; ++u) {
+                const unsigned rel = (r[u].xy & 0xffffu) * (unsigned)rows + (r[u].xy >> 16) - seg0;
+                if (r[u].xy != 0xffffffffu && rel < seg_keys) atomicOr(&bits[rel >> 5], 1u << (rel & 31u));
+            }
+            __syncthreads();
+            const int w0 = threadIdx.x * wpt, w1 = min(words, w0 + wpt);
+            int tot = 0;
+            for (int w = w0; w < w1; ++w) tot += __popc(bits[w]);
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int run = incl - tot;
+            for (int w = 0; w < wave; ++w) run += wsum[w];
+            const int base = s_base;
+            for (int w = w0; w < w1; ++w) {
+                wpre[w] = run;
+                run += __popc(bits[w]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SORT_U; ++u) {
+                const unsigned rel = (r[u].xy & 0xffffu) * (unsigned)rows + (r[u].xy >> 16) - seg0;
+                if (r[u].xy != 0xffffffffu && rel < seg_keys) {
+                    const unsigned w = rel >> 5;
+                    rank[u] = base + wpre[w] + __popc(bits[w] & ((1u << (rel & 31u)) - 1u));
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == SORT_BLOCK - 1) s_base = base + run;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; ++u)
+            if (rank[u] >= 0 && rank[u] < n) S[rank[u]] = r[u];  // (every record of the list is in some thread's registers: in place)
+        return;
+    }
     for (unsigned seg0 = 0; seg0 < nkeys; seg0 += SORT_WORDS * 32u) {
         const unsigned seg_keys = min(nkeys - seg0, SORT_WORDS * 32u);
         const int words = (int)((seg_keys + 31u) >> 5);
