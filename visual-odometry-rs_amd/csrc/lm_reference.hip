@@ -225,7 +225,7 @@ __device__ void ref_eval(const Src& src, int n, const RefImg& c, const Iso& mode
                     }
                 }
             }
-        } else if (ch > 0) {  // consume chunk ch - 1: the sequential sums, one lane per sum
+        } else if (ch > 0 && lane < 32) {  // consume chunk ch - 1: the sequential sums, one lane per sum (the upper half-wavefront sits out: its LDS requests would cost the same again)
             const float* rows = buf + ((ch - 1) & 1) * (REF_CH * RS);
             const int m = min(REF_CH, n - (ch - 1) * REF_CH);
             int i = 0;
