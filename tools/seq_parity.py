@@ -54,6 +54,8 @@ for mode in modes:
         mk = lambda a: V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode_id, arithmetic=a)
         res = {"fused (warp chain on small levels)": run(mk(V.ARITH_FUSED), frames),
                "fused, VORS_FUSED_SMALL=exact": run(mk(V.ARITH_FUSED), frames, {"VORS_FUSED_SMALL": "exact"}),
+               **{f"fused, VORS_FUSED_EXACT_POINTS={t}": run(mk(V.ARITH_FUSED), frames, {"VORS_FUSED_EXACT_POINTS": t})
+                  for t in os.environ.get("THRESHOLDS", "").split(",") if t},
                "exact": run(mk(V.ARITH_EXACT), frames), "oracle f64 sums": ref64}
         line = []
         for name, traj in res.items():
