@@ -676,10 +676,44 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = hv[g] * rz[g];
     if (XW || VORS_ABL_EXACT_WARP) {
+#ifndef VORS_XW_PLAIN_DIV
+#define VORS_XW_PLAIN_DIV 1
+#endif
+        if constexpr (XW && VORS_XW_PLAIN_DIV) {
+            // The three per-point divisions of the reference's chain (1 / _z, pu / z', pv / z') as the IEEE sequence WITHOUT its range scaling
+            // and special-case fix-up (v_div_scale x 2, v_div_fmas, v_div_fixup): reciprocal, one Newton step, product, two fused
+            // corrections — the very operations v_div_* perform when no scaling is needed, i.e. for every operand a depth or a projected
+            // coordinate can take; the two quotients by z' share the refined reciprocal. 21 instead of 33 instructions per point, the same
+            // quotients bit for bit (tools/ab_bits.py: poses identical to the IEEE build).
+            auto refine = [](float d) {
+                const float r0 = __builtin_amdgcn_rcpf(d);
+                return fmaf(fmaf(-d, r0, 1.0f), r0, r0);
+            };
+            auto quot = [](float n, float d, float r) {
+                const float q0 = n * r;
+                const float q1 = fmaf(fmaf(-d, q0, n), r, q0);
+                return fmaf(fmaf(-d, q1, n), r, q1);
+            };
+            float zc[G];
+            V3 Pw[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const V3 P = XW ? back_project_rt(IntrFast{c.k, dfu, dfv}, p.px[g], p.py[g], 1.0f / p.iz[g]) : back_project(c.k, p.px[g], p.py[g], 1.0f / p.iz[g]);
-            project_uv(c.k, iso_transform_point(model, P), &u[g], &v[g]);
+            for (int g = 0; g < G; ++g) zc[g] = quot(1.0f, p.iz[g], refine(p.iz[g]));
+#pragma unroll
+            for (int g = 0; g < G; ++g) Pw[g] = iso_transform_point(model, back_project_rt(IntrFast{c.k, dfu, dfv}, p.px[g], p.py[g], zc[g]));
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float pu = (c.k.fu * Pw[g].x + c.k.skew * Pw[g].y) + c.k.cu * Pw[g].z;  // project: camera.rs:126-132, as lie.h project_uv
+                const float pv = c.k.fv * Pw[g].y + c.k.cv * Pw[g].z;
+                const float r = refine(Pw[g].z);
+                u[g] = quot(pu, Pw[g].z, r);
+                v[g] = quot(pv, Pw[g].z, r);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const V3 P = XW ? back_project_rt(IntrFast{c.k, dfu, dfv}, p.px[g], p.py[g], 1.0f / p.iz[g]) : back_project(c.k, p.px[g], p.py[g], 1.0f / p.iz[g]);
+                project_uv(c.k, iso_transform_point(model, P), &u[g], &v[g]);
+            }
         }
     }
 #pragma unroll
