@@ -681,10 +681,10 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
 #endif
         if constexpr (XW && VORS_XW_PLAIN_DIV) {
             // The three per-point divisions of the reference's chain (1 / _z, pu / z', pv / z') as the IEEE sequence WITHOUT its range scaling
-            // and special-case fix-up (v_div_scale x 2, v_div_fmas, v_div_fixup): reciprocal, one Newton step, product, two fused
-            // corrections — the very operations v_div_* perform when no scaling is needed, i.e. for every operand a depth or a projected
-            // coordinate can take; the two quotients by z' share the refined reciprocal. 21 instead of 33 instructions per point, the same
-            // quotients bit for bit (tools/ab_bits.py: poses identical to the IEEE build).
+            // (v_div_scale x 2, v_div_fmas): reciprocal, one Newton step, product, two fused corrections, v_div_fixup — the very operations
+            // the compiler's expansion performs when no scaling is needed, i.e. for every operand a depth or a projected coordinate can take;
+            // the two quotients by z' share the refined reciprocal. 24 instead of 33 instructions per point, the same quotients bit for bit
+            // (tools/ab_bits.py: poses identical to the IEEE build).
             auto refine = [](float d) {
                 const float r0 = __builtin_amdgcn_rcpf(d);
                 return fmaf(fmaf(-d, r0, 1.0f), r0, r0);
@@ -692,7 +692,9 @@ __device__ __forceinline__ void fused_stage_b(const FUnit<G>& p, const ImgCtx& c
             auto quot = [](float n, float d, float r) {
                 const float q0 = n * r;
                 const float q1 = fmaf(fmaf(-d, q0, n), r, q0);
-                return fmaf(fmaf(-d, q1, n), r, q1);
+                // (v_div_fixup stays: a divisor of exactly 0, an infinity or a NaN must give the IEEE result — x / 0 = inf is OUTSIDE the image,
+                // the NaN the bare sequence would produce converts to column 0)
+                return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-d, q1, n), r, q1), d, n);
             };
             float zc[G];
             V3 Pw[G];
