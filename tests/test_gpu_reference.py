@@ -82,6 +82,30 @@ def test_candidate_lists_come_out_in_extract_z_order(mode, rows, cols, L):
             assert (np.diff(key) > 0).all()
 
 
+@pytest.mark.parametrize("mode", [0, 2], ids=["coarse_to_fine", "dso"])
+def test_both_forms_of_the_column_major_sort_give_the_same_lists(monkeypatch, mode):
+    """Round 4: sort_colmajor_kernel keeps lists of at most 4096 records in registers and writes them back in place; longer lists take the
+    multi-pass form through the scratch copy, which VORS_REF_SORT_REGCAP=0 forces for every list (1000: level 0 only). Same lists, hence
+    the same poses bit for bit — and both equal the oracle's."""
+    rows, cols, L, n = 480, 640, 6, 6
+    intr = O.scaled_intrinsics(rows, cols)
+    kg, kd, cg, cd, gt = synth(n, rows, cols, intr, 0x5EED7700, blocky=(mode == 2))
+    ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg, kd, cg)
+    res = {}
+    for cap in ("", "0", "1000"):
+        if cap:
+            monkeypatch.setenv("VORS_REF_SORT_REGCAP", cap)
+        else:
+            monkeypatch.delenv("VORS_REF_SORT_REGCAP", raising=False)
+        b, poses, status, stats, _ = run_batch(vcfg(L, intr, mode), kg, kd, cg)
+        assert_pairs_identical(ref, poses, status, stats, L, f"sort form {cap or 'default'}")
+        res[cap] = [[b.points(p, l)[0] for l in range(L)] for p in range(n)]
+    for cap in ("0", "1000"):
+        for p in range(n):
+            for l in range(L):
+                assert (res[cap][p][l] == res[""][p][l]).all(), (cap, p, l)
+
+
 # ---------------------------------------------------------------------------------------------- operator level
 @pytest.mark.parametrize("huber", [0.0, 10.0], ids=["l2", "huber10"])
 def test_lm_eval_and_solve_on_explicit_observations_equal_the_oracle_bit_for_bit(huber):

@@ -26,6 +26,9 @@
 // Compile with -ffp-contract=off (no FMA may be formed from the consumer's multiply + add).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_common.h"
 #include "engine.h"
 
@@ -567,7 +570,7 @@ void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* im
 #define SORT_WORDS 4096  // 131,072 keys per segment: 16 KB of bits + 16 KB of word prefixes
 #define SORT_BLOCK 512
 #define SORT_U 8          // independent loads in flight per thread (a pass is a chain of global round trips otherwise)
-__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void sort_colmajor_kernel(Geom g, Records rec) {
+__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void sort_colmajor_kernel(Geom g, Records rec, int reg_cap) {
     __shared__ uint32_t bits[SORT_WORDS];
     __shared__ int wpre[SORT_WORDS];  // set bits in the words before this one (within the segment)
     __shared__ int wsum[SORT_BLOCK / 64];
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6)))
     SlimRec* T = rec.sort_tmp + lvl0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
-    if (n <= SORT_BLOCK * SORT_U) {
+    if (n <= reg_cap) {  // (reg_cap <= SORT_BLOCK * SORT_U: launch_sort_colmajor)
         // Round 4: a list of at most 4096 records (every level of the reference's shapes) stays in REGISTERS — 8 records per thread — while the
         // segments of the key space go by; each record learns its rank in its segment, and the list is written back IN PLACE at the end. One read
         // and one write of the list instead of a read per segment and pass, a scratch copy and a copy back: 3.5 GB of traffic per 4096
@@ -724,7 +727,12 @@ __global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6)))
 }
 void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s) {
     if (g.mode == VORS_CANDIDATES_DENSE || !rec.sort_tmp) return;
-    hipLaunchKernelGGL(sort_colmajor_kernel, dim3(g.L, n_pairs), dim3(SORT_BLOCK), 0, s, g, rec);
+    // VORS_REF_SORT_REGCAP (read per launch; tests): lists longer than this take the multi-pass form through the scratch copy — 0 forces it
+    // for every list; the default is what 8 records per thread hold
+    const char* e = getenv("VORS_REF_SORT_REGCAP");
+    int reg_cap = SORT_BLOCK * SORT_U;
+    if (e) reg_cap = std::max(0, std::min(reg_cap, atoi(e)));
+    hipLaunchKernelGGL(sort_colmajor_kernel, dim3(g.L, n_pairs), dim3(SORT_BLOCK), 0, s, g, rec, reg_cap);
 }
 
 }  // namespace vors
