@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where do the wavefronts of the per-pair LM kernels wait?  Three rocprofv3 --pmc passes (kernel trace only) of a bench.py workload, LM-stage
 # kernels summed per counter, plus derived ratios (average LDS / VMEM instruction latency = level sum / instruction count). Development aid,
-# run through gpurun:   bash tools/pmc_wait.sh TAG --candidates c2f --arith reference
+# run through gpurun:   [KERNELS='regex of kernel names'] bash tools/pmc_wait.sh TAG --candidates c2f --arith reference
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_wait_$TAG; mkdir -p $OUT
@@ -17,7 +17,9 @@ for p in ("p1","p2","p3"):
     if not fs: print(p,"no csv"); print(open(f"$OUT/{p}.log").read()[-400:]); continue
     for r in csv.DictReader(open(fs[0])):
         k=r["Kernel_Name"]
-        if "lm_track_kernel" in k or "lm_ref_track_kernel" in k or "lm_split" in k:
+        import os, re
+        pat = os.environ.get("KERNELS", "lm_track_kernel|lm_ref_track_kernel|lm_split")
+        if re.search(pat, k):
             tot[r["Counter_Name"]]+=float(r["Counter_Value"]); names.add(k[k.find("vors::"):][:60])
 print("$TAG kernels:", sorted(names))
 for k in sorted(tot): print(f"  {k:24s} {tot[k]:.4g}")

@@ -55,7 +55,7 @@ __device__ __forceinline__ void grad_tmpl_at(const Geom& g, const uint8_t* level
     if (l == 0) {
         const int rows = g.lv[0].rows, cols = g.lv[0].cols;
         const uint8_t* p = level0 + (size_t)pair * g.S0;
-        const unsigned o = (unsigned)(y * cols + x);
+        const unsigned o = __umul24((unsigned)y, (unsigned)cols) + (unsigned)x;
         const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
         const unsigned dx = interior ? 1u : 0u, dy = interior ? (unsigned)cols : 0u;
         const int l0 = p[o - dx], r0 = p[o + dx], u0 = p[o - dy], d0 = p[o + dy];
@@ -65,7 +65,7 @@ __device__ __forceinline__ void grad_tmpl_at(const Geom& g, const uint8_t* level
     } else {
         const int fc = g.lv[l - 1].cols;
         const uint8_t* pb = level_ptr(g, level0, upper, pair, l - 1);
-        const unsigned o = (unsigned)((2 * y) * fc + 2 * x);
+        const unsigned o = __umul24((unsigned)(2 * y), (unsigned)fc) + (unsigned)(2 * x);  // (24-bit multiply: full rate; v_mul_lo_u32 is quarter rate)
         const uint8_t* p = pb + o;
         uint16_t r0, r1;  // the 2x2 block as two (possibly unaligned) 16-bit loads instead of four byte loads
         __builtin_memcpy(&r0, p, 2);

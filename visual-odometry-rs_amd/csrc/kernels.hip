@@ -445,8 +445,9 @@ __global__ __launch_bounds__(256) void compact_regions_kernel(Geom g, Records re
             s_pre[threadIdx.x] = pre;
             __syncthreads();
             const int n_tile = min(256, rec.n_regions - tile);
+            const int cap_sh = __ffs(cap_r) - 1;  // (cap_r = roots per region << level distance: a power of two — a shift, not a ~30-instruction division per record)
             for (int j = threadIdx.x; j < n_tile * cap_r; j += 256) {
-                const int rr = j / cap_r, k = j - rr * cap_r;
+                const int rr = j >> cap_sh, k = j & (cap_r - 1);
                 if (k < s_cnt[rr]) dst[s_pre[rr] + k] = src[(size_t)(tile + rr) * cap_r + k];
             }
             __syncthreads();
