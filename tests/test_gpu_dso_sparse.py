@@ -81,9 +81,10 @@ def test_threads_per_pair_of_the_selector_and_records_kernels_do_not_change_the_
     """Large batches run the selection rounds and the records kernel with 512 threads per pair, small ones with 1024 (scheduling only):
     same candidates, same values, same order, hence the same poses bit for bit."""
     a = run(tmp_path, "t1024", False, rows, cols, L, threads=(1024, 1024))
-    b = run(tmp_path, "t512", False, rows, cols, L, threads=(512, 512))
-    for key in a.files:
-        assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key
+    for tag, threads in (("t512", (512, 512)), ("t768", (768, 512))):  # (768: round 4's choice for the selection rounds from 512 pairs on)
+        b = run(tmp_path, tag, False, rows, cols, L, threads=threads)
+        for key in a.files:
+            assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), (tag, key)
 
 
 @pytest.mark.parametrize("rows,cols,L,threads", [(480, 640, 6, (512, 512)), (480, 640, 6, (1024, 1024)), (121, 163, 4, None), (960, 1280, 7, None), (64, 96, 2, None)])

@@ -526,11 +526,14 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
         hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
     }
     // Threads per pair: the kernel is a chain of short phases over planes in global memory with a barrier between them; a large batch
-    // runs faster with more, smaller workgroups per CU to interleave (4096 pairs: 1.17 -> 1.02 ms with 512 threads), a small one with
-    // the shortest chain per pair (<= 1024 pairs: 1024 threads win by 2-20 %). Results do not depend on it.
+    // runs faster with more, smaller workgroups per CU to interleave (round 3, 4096 pairs: 1.17 -> 1.02 ms with 512 threads), a small one
+    // with the shortest chain per pair. Results do not depend on it.
     const char* e = getenv("VORS_DSO_ROUNDS_THREADS");
     const int forced = e ? atoi(e) : 0;
-    const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 2048 ? 512 : 1024);
+    // Round 4, sweep over 64 .. 1024 threads in steps of 64 at 64 / 512 / 2048 / 4096 pairs (profiles/r04_dso_rounds_threads.log): 768 threads
+    // — twelve wavefronts, three per SIMD, two workgroups per CU — are fastest from 512 pairs on (4096 pairs: step 5.00 ms with 512 threads,
+    // 5.06 with 1024, 4.84 with 768), 1024 for the small batches (the shortest chain per pair).
+    const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 512 ? 768 : 1024);
     hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out);
 }
 // ------------------------------------------------------------------------------------------------------------
