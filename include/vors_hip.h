@@ -202,12 +202,19 @@ typedef struct vors_batch vors_batch;
  *                                (same candidates and values; the lists then come out in raster instead of Morton order)
  *   VORS_DSO_SCAN=1              DSO mode: the usable picks from a pass over the stamp plane instead of the selection rounds' own list
  *                                (identical lists)
- *   VORS_DSO_ROUNDS_THREADS=n    DSO mode: threads per pair in the selection-rounds kernel (default 512 from 2048 pairs on, else 1024)
+ *   VORS_DSO_ROUNDS_THREADS=n    DSO mode: threads per pair in the selection-rounds kernel, a multiple of 64 (default 768 from 512 pairs on,
+ *                                else 1024: profiles/r04_dso_rounds_threads.log; read per launch)
+ *   VORS_DSO_SORT=bitonic        DSO mode: the pick list ordered by round 3's bitonic network instead of the bucket sort (identical lists;
+ *                                read per launch)
+ *   VORS_REF_SORT_REGCAP=n       REFERENCE arithmetic: lists longer than n records take the multi-pass form of the column-major sort
+ *                                (default 4096 = what the register-resident form holds; identical lists; read per launch)
  *   VORS_DSO_RECORDS_THREADS=512|1024  DSO mode: threads per pair in the sparse records kernel (default 512 from 512 pairs on, else 1024)
  *   VORS_PYRAMID_FUSED=0         mean pyramid one level per launch instead of up to five halvings in one (bit-identical; read once per process)
  *   VORS_IDEPTH_LEVEL12=1        dense mode: inverse-depth levels 1-2 in one pass + a halving launch instead of levels 1-3 in one (bit-identical)
- *   VORS_FUSED_EXACT_POINTS=n    FUSED arithmetic: levels of at most n points are evaluated in the EXACT arithmetic (default 2500; 0 = the
- *                                round-2 behaviour, which leaves ~0.2 % of coarse-to-fine pairs beyond 1e-4: DESIGN.md §4) */
+ *   VORS_FUSED_EXACT_POINTS=n    FUSED arithmetic: levels of at most n points take (u, v) from the reference's own warp chain (candidate
+ *                                lists) or run the whole EXACT evaluation (dense pixel levels); default 2500, re-derived in round 4 on
+ *                                six draws of 64 sequences + 4096 pairs (profiles/r04_parity_sequences.md); 0 = the round-2 behaviour
+ *   VORS_FUSED_SMALL=exact       FUSED arithmetic, candidate lists: the whole EXACT evaluation on those levels (round 3's rule) */
 vors_status vors_batch_create(const vors_config* cfg, int max_pairs, int rows, int cols, vors_batch** out);
 /* Same on an explicit HIP device (vors_batch_create = the calling thread's current device). The handle remembers its device: every
  * entry point switches to it for the call and restores the caller's current device; a hip_stream of another device is rejected with
