@@ -10,6 +10,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 bad = 0
+n_ref_identical = 0
 for i in range(n_cases):
     rows, cols = int(rng.integers(24, 300)), int(rng.integers(32, 400))
     if rng.random() < 0.4: cols = (cols // 16) * 16 or 32
@@ -18,7 +19,7 @@ for i in range(n_cases):
     intr = O.scaled_intrinsics(rows, cols)
     kg, kd, cg, cd, gt = O.synth_batch(2, rows, cols, seed0=((1 << 63) if MODE == 2 else 0) | (0x5EEDAA00 + 8 * i), intr=intr)
     ref = O.track_pairs(O.make_config(L, intr, candidates_mode=MODE), kg, kd, cg)
-    for arith in (0, 1):
+    for arith in (0, 1, 2):  # EXACT, FUSED: within 1e-4; REFERENCE: the oracle's bits
         cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=MODE, arithmetic=arith)
         b = V.Batch(cfg, 2, rows, cols)
         t = [torch.from_numpy(np.ascontiguousarray(kg)).cuda(), torch.from_numpy(np.ascontiguousarray(kd).view(np.int16)).cuda(), torch.from_numpy(np.ascontiguousarray(cg)).cuda()]
@@ -28,9 +29,16 @@ for i in range(n_cases):
         ok = (status.cpu().numpy() == ref["status"]).all() and (st["n_points"][:, :L] == ref["n_points"]).all()
         good = ref["status"] == 0
         err = np.abs(poses.cpu().numpy() - ref["poses"])[good].max(initial=0)
+        if arith == 2:
+            same = (poses.cpu().numpy().view(np.uint32) == ref["poses"].view(np.uint32))[good].all() and (st["nb_iter"][:, :L] == ref["nb_iter"])[good].all()
+            n_ref_identical += int(bool(ok and same))
+            if not (ok and same):
+                bad += 1
+                print(f"REFERENCE NOT IDENTICAL case {i}: {cols}x{rows} L{L}: status {status.cpu().numpy()} vs {ref['status']}, pose err {err:.2e}, iterations oracle {ref['nb_iter'].tolist()} gpu {st['nb_iter'][:, :L].tolist()}")
+            continue
         if not ok or err > 1e-4:
             bad += 1
             rv = O.track_pairs(O.make_config(L, intr, candidates_mode=MODE), kg, kd, cg, variant="acc64")  # the oracle's own sensitivity build
             print(f"   (oracle[acc64] vs oracle on these pairs: {np.abs(rv['poses'] - ref['poses'])[good].max(initial=0):.2e}; iterations oracle {ref['nb_iter'].tolist()} gpu {st['nb_iter'][:, :L].tolist()})")
             print(f"MISMATCH case {i}: {cols}x{rows} L{L} arith {arith}: status {status.cpu().numpy()} vs {ref['status']}, points {st['n_points'][:, :L].tolist()} vs {ref['n_points'].tolist()}, pose err {err:.2e}")
-print(f"mode {MODE}: {n_cases} shapes x 2 arithmetics: {bad} mismatches")
+print(f"mode {MODE}: {n_cases} shapes x 3 arithmetics: {bad} mismatches; REFERENCE arithmetic bit-identical to the oracle (poses, iteration counts) in {n_ref_identical} of {n_cases} shapes")
