@@ -34,21 +34,11 @@
 
 namespace vors {
 
-#define REF_BLOCK 256
-#define REF_PROD (REF_BLOCK - 64)  // producer threads: wavefronts 1..3
-#define REF_G 2                    // points per producer thread and chunk
-#define REF_CH (REF_PROD * REF_G)  // points per chunk
-template <bool HUBER>
-struct RefRow {
-    // plain: [r, J0..J5, -]        Huber: [loss term, w r, J0..J5, w, 1, -, -]
-    static constexpr int RS = HUBER ? 12 : 8;
-};
-
-struct RefShared {
-    float sums[2][32];  // ping-pong totals as in lm_kernels.hip: 0 = sum r^2, 1 = n_inside, 2..7 = g, 8..28 = H upper triangle row-wise
-    float cand[8];      // candidate model (7) + step-ok flag
-    int cnt;
-};
+// ---- the wavefront-private transposition buffer -------------------------------------------------------------------------------------
+#define RW_WPB 4                         // independent wavefronts (= frame pairs) per workgroup, at most
+#define RW_NSUM 28                       // sums: 0 = sum r^2 (Huber: loss), 1..6 = g, 7..27 = H upper triangle row-wise
+#define RW_STRIDE 68                     // words per product row: 64 points + 4 (see refw_eval: conflict-free ds_read_b128 by lanes 0..27)
+#define RW_WORDS (RW_NSUM * RW_STRIDE)   // 7,616 bytes per wavefront
 
 struct RefImg {  // the current image of a level + its intrinsics
     const uint8_t* img;
@@ -57,25 +47,24 @@ struct RefImg {  // the current image of a level + its intrinsics
     float huber;
 };
 
-struct RefPt {
-    V3 P;        // back-projected keyframe point (camera.rs:135-140)
-    float tmpl;  // template grey level
-    float J[6];  // warp Jacobian (inverse_compositional.rs:313-341)
-    bool valid;
-};
-
-// ---- point providers: point i of the level, in the reference's order --------------------------------------------------------------
-struct RefSlimSrc {  // sparse modes: the sorted 12-byte lists
+// ---- point providers: point i of the level, in the reference's order. Three steps, so that refw_eval can keep the memory round trips of
+// the NEXT 64 points in flight while it works on the current ones:
+//   load(i)   issues the loads of everything the point is made of -> Raw (registers)
+//   point()   the back-projected keyframe point (camera.rs:135-140) + whether the slot holds a candidate
+//   jac()     the warp Jacobian (inverse_compositional.rs:313-341) + the template grey level
+struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
     const SlimRec* S;
     Intr k;
     FastDiv fu, fv;  // the focal lengths as verified fast divisors (lie.h div_uniform: bit-identical to the IEEE quotient, or `ok` = 0)
-    __device__ __forceinline__ void get(int i, RefPt& p) const {
-        const SlimRec r = S[(unsigned)i];
-        const float x = (float)(r.xy & 0xffffu), y = (float)(r.xy >> 16);
-        p.P = back_project_rt(IntrFast{k, fu, fv}, x, y, 1.0f / r.iz);
-        p.tmpl = (float)(r.tg & 0xffu);
-        warp_jacobian_at_rt((float)slim_gx(r.tg), (float)slim_gy(r.tg), x, y, r.iz, IntrFast{k, fu, fv}, p.J);
-        p.valid = true;
+    typedef SlimRec Raw;
+    __device__ __forceinline__ Raw load(int i) const { return S[(unsigned)i]; }
+    __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
+        *P = back_project_rt(IntrFast{k, fu, fv}, (float)(r.xy & 0xffffu), (float)(r.xy >> 16), 1.0f / r.iz);
+        *valid = true;
+    }
+    __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
+        *tmpl = (float)(r.tg & 0xffu);
+        warp_jacobian_at_rt((float)slim_gx(r.tg), (float)slim_gy(r.tg), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, IntrFast{k, fu, fv}, J);
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* iz, bool* valid) const {
         const SlimRec r = S[(unsigned)i];
@@ -93,6 +82,11 @@ struct RefDenseSrc {  // dense mode: pixel i of the column-major enumeration, re
     const float* iz;        // levels >= 1, this pair and level (row-major), NaN = Unknown
     int pair, lvl, rows, cols;
     Intr k;
+    struct Raw {
+        uint32_t xy;   // x | y << 16
+        float iz;      // inverse depth (anything when !valid)
+        uint32_t tgv;  // slim_pack_tg(template, gx, gy) | valid << 31
+    };
     __device__ __forceinline__ void raw(int i, int* x, int* y, float* izv, bool* valid) const {
         const int xx = i / rows, yy = i - xx * rows;
         *x = xx;
@@ -107,15 +101,21 @@ struct RefDenseSrc {  // dense mode: pixel i of the column-major enumeration, re
             *izv = z;
         }
     }
-    __device__ __forceinline__ void get(int i, RefPt& p) const {
-        int x, y;
+    __device__ __forceinline__ Raw load(int i) const {
+        int x, y, gx, gy, tm;
         float izv;
-        raw(i, &x, &y, &izv, &p.valid);
-        int gx, gy, tm;
+        bool valid;
+        raw(i, &x, &y, &izv, &valid);
         grad_tmpl_at(*g, kf0, kfu, pair, lvl, x, y, &gx, &gy, &tm);
-        p.P = back_project(k, (float)x, (float)y, 1.0f / izv);
-        p.tmpl = (float)tm;
-        warp_jacobian_at((float)gx, (float)gy, (float)x, (float)y, izv, k, p.J);
+        return Raw{(uint32_t)x | ((uint32_t)y << 16), izv, slim_pack_tg(tm, gx, gy) | (valid ? 0x80000000u : 0u)};
+    }
+    __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
+        *P = back_project(k, (float)(r.xy & 0xffffu), (float)(r.xy >> 16), 1.0f / r.iz);
+        *valid = (r.tgv >> 31) != 0u;
+    }
+    __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
+        *tmpl = (float)(r.tgv & 0xffu);
+        warp_jacobian_at((float)slim_gx(r.tgv), (float)slim_gy(r.tgv), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, k, J);
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* izv, bool* valid) const {
         int xi, yi;
@@ -128,138 +128,195 @@ struct RefObsSrc {  // operator level: explicit observations in the caller's ord
     const float4* A;
     const float4* B;
     const float2* C;
-    __device__ __forceinline__ void get(int i, RefPt& p) const {
-        const float4 a = A[(unsigned)i], b = B[(unsigned)i];
-        const float2 c = C[(unsigned)i];
-        p.P = V3{a.x, a.y, a.z};
-        p.tmpl = a.w;
-        p.J[0] = b.x; p.J[1] = b.y; p.J[2] = b.z; p.J[3] = b.w; p.J[4] = c.x; p.J[5] = c.y;
-        p.valid = a.w >= 0.f;
+    struct Raw {
+        float4 a, b;
+        float2 c;
+    };
+    __device__ __forceinline__ Raw load(int i) const { return Raw{A[(unsigned)i], B[(unsigned)i], C[(unsigned)i]}; }
+    __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
+        *P = V3{r.a.x, r.a.y, r.a.z};
+        *valid = r.a.w >= 0.f;
+    }
+    __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
+        *tmpl = r.a.w;
+        J[0] = r.b.x; J[1] = r.b.y; J[2] = r.b.z; J[3] = r.b.w; J[4] = r.c.x; J[5] = r.c.y;
     }
 };
 
-// warp (lm_optimizer.rs:213-219) + interpolate (lm_optimizer.rs:227-251) + residual of one point -> its row. Returns inside.
-template <bool HUBER>
-__device__ __forceinline__ bool ref_point_row(const RefPt& p, const RefImg& c, const Iso& model, float* row, float* res_out) {
+// warp (lm_optimizer.rs:213-219) of one point and the REQUESTS for the four grey levels interpolate (lm_optimizer.rs:227-251) will read:
+// two 16-bit loads (left | right << 8 of the upper and of the lower row).
+struct RefTap {
+    float fa, fb;     // u - floor(u), v - floor(v)
+    uint32_t t0, t1;  // taps of row floor(v) and of the row below
+    bool inside;
+};
+__device__ __forceinline__ RefTap refw_warp(const V3& P, bool valid, const RefImg& c, const Iso& model) {
     float u, v;
-    project_uv(c.k, iso_transform_point(model, p.P), &u, &v);
+    project_uv(c.k, iso_transform_point(model, P), &u, &v);
     const float uf = floorf(u), vf = floorf(v);
-    const bool inside = p.valid && (uf >= 0.f) && (uf < (float)(c.cols - 2)) && (vf >= 0.f) && (vf < (float)(c.rows - 2));
-    const unsigned off = inside ? (unsigned)((int)vf * c.cols + (int)uf) : 0u;
-    const float vu_00 = (float)c.img[off], vu_01 = (float)c.img[off + 1u];
-    const float vu_10 = (float)c.img[off + (unsigned)c.cols], vu_11 = (float)c.img[off + (unsigned)c.cols + 1u];
-    const float fa = u - uf, fb = v - vf;
+    RefTap t;
+    t.inside = valid && (uf >= 0.f) && (uf < (float)(c.cols - 2)) && (vf >= 0.f) && (vf < (float)(c.rows - 2));
+    const unsigned off = t.inside ? (unsigned)((int)vf * c.cols + (int)uf) : 0u;
+    uint16_t a, b;
+    __builtin_memcpy(&a, c.img + off, 2);
+    __builtin_memcpy(&b, c.img + (off + (unsigned)c.cols), 2);
+    t.t0 = a;
+    t.t1 = b;
+    t.fa = u - uf;
+    t.fb = v - vf;
+    return t;
+}
+
+// interpolate + residual, then the 28 PRODUCTS the reference adds to its sums for this point — each rounded once, exactly the values of
+// `r * r` (lm_optimizer.rs:80), `jac * r` (lm_optimizer.rs:98) and `jac * jac^T` (inverse_compositional.rs:347); Huber extension: loss term,
+// jac * (w r), w * (jac * jac^T) like the oracle. An outside point contributes +0 to every sum (its residual and Jacobian are replaced by
+// +0, so every product is +0): adding +0 is exact (a running sum that starts at +0 never becomes -0), so it equals skipping the point.
+template <bool HUBER>
+__device__ __forceinline__ void refw_products(const RefTap& t, float tmpl, const float Jin[6], float huber, float pr[RW_NSUM], float* res_out) {
+    const float vu_00 = (float)(t.t0 & 0xffu), vu_01 = (float)(t.t0 >> 8);
+    const float vu_10 = (float)(t.t1 & 0xffu), vu_11 = (float)(t.t1 >> 8);
+    const float fa = t.fa, fb = t.fb;
     const float im = (1.0f - fb) * (1.0f - fa) * vu_00 + fb * (1.0f - fa) * vu_10 + (1.0f - fb) * fa * vu_01 + fb * fa * vu_11;
-    const float r = im - p.tmpl;
-    if (res_out) *res_out = inside ? r : __builtin_nanf("");
+    const float r_in = im - tmpl;
+    if (res_out) *res_out = t.inside ? r_in : __builtin_nanf("");
+    const float r = t.inside ? r_in : 0.f;
+    float J[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) J[q] = t.inside ? Jin[q] : 0.f;
+    float e, wr, w = 1.0f;
     if (HUBER) {  // extension (oracle: lm_optimizer restatement, eval_energy / compute_eval_data with huber_delta)
         const float ar = fabsf(r);
-        const bool quad = ar <= c.huber;
-        const float e = quad ? r * r : c.huber * (2.0f * ar - c.huber);
-        const float w = quad ? 1.0f : c.huber / ar;
-        float4* q = reinterpret_cast<float4*>(row);
-        q[0] = inside ? make_float4(e, w * r, p.J[0], p.J[1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        q[1] = inside ? make_float4(p.J[2], p.J[3], p.J[4], p.J[5]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        q[2] = make_float4(inside ? w : 1.0f, 1.0f, 0.f, 0.f);
+        const bool quad = ar <= huber;
+        e = quad ? r * r : huber * (2.0f * ar - huber);
+        w = quad ? 1.0f : huber / ar;
+        wr = w * r;
     } else {
-        float4* q = reinterpret_cast<float4*>(row);
-        q[0] = inside ? make_float4(r, p.J[0], p.J[1], p.J[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        q[1] = inside ? make_float4(p.J[3], p.J[4], p.J[5], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        e = r * r;
+        wr = r;
     }
-    return inside;
-}
-
-// Which two (three) row entries the consumer lane multiplies: lane 0 = energy, 1..6 = g, 7..27 = H upper triangle row-wise.
-template <bool HUBER>
-__device__ __forceinline__ void ref_lane_slots(int lane, int* a, int* b, int* w) {
-    int q = 0, s2 = 0;
-    if (lane >= 7) {  // h = lane - 7 -> (q, s2), q <= s2, row-wise
-        int h = lane - 7;
-        q = 0;
-        int len = 6;
-        while (h >= len && q < 5) {
-            h -= len;
-            len -= 1;
-            q += 1;
+    pr[0] = e;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pr[1 + q] = J[q] * wr;
+    int k = 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int s2 = q; s2 < 6; ++s2) {
+            const float jj = J[q] * J[s2];
+            pr[k++] = HUBER ? w * jj : jj;
         }
-        s2 = q + h;
-    }
-    if (HUBER) {
-        if (lane == 0) { *a = 0; *b = 9; *w = 9; }            // loss term * 1 * 1
-        else if (lane < 7) { *a = 1 + lane; *b = 1; *w = 9; }  // jac[q] * (w r) * 1
-        else { *a = 2 + q; *b = 2 + s2; *w = 8; }              // w * (jac[q] * jac[s])
-        if (lane >= 28) { *a = 9; *b = 9; *w = 9; }
-    } else {
-        if (lane == 0) { *a = 0; *b = 0; }               // r * r
-        else if (lane < 7) { *a = lane; *b = 0; }        // jac[q] * r
-        else { *a = 1 + q; *b = 1 + s2; }                // jac[q] * jac[s]
-        if (lane >= 28) { *a = 7; *b = 7; }
-        *w = 0;
-    }
 }
 
-// One evaluation: eval_energy + compute_eval_data (lm_optimizer.rs:68-107) of the n points of `src` at `model`, sums in list order
-// -> s.sums[dst][0..28]. All REF_BLOCK threads call it; ends with a barrier.
+// Orders this wavefront's LDS stores before its later LDS loads and the other way round. The hardware executes one wavefront's DS
+// instructions in order; this only stops the compiler from moving them across (no instruction is emitted).
+__device__ __forceinline__ void refw_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float refw_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// A copy the compiler cannot fold away. refw_eval keeps ONE register set for the record request in flight: it is read (here) at the top of a
+// trip, which ends the life of the old value, and requested again a few instructions later. Without the real move the old value lives on
+// under the same name (as the record of the group being summed), the new request gets other registers and the copy back into the loop's
+// registers — placed at the end of the trip — waits for the request: the pipeline would be gone.
+template <class T>
+__device__ __forceinline__ T refw_moved(const T& v) {
+    static_assert(sizeof(T) % 4 == 0, "dwords");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "v"(w[i]));
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+
+#ifdef VORS_REFW_TIMING  // development build (tools/build_ref_variant.sh): shader cycles per phase, summed over all wavefronts
+__device__ unsigned long long refw_prof[8];  // 0 eval cycles, 1 step cycles, 2 groups of 64 points, 3 evaluations, 4 kernel cycles, 5 wavefronts
+#define REFW_T0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define REFW_ADD(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&refw_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define REFW_T0(v)
+#define REFW_ADD(slot, v)
+#endif
+
+// One evaluation — eval_energy + compute_eval_data (lm_optimizer.rs:68-107) — of the n points of `src` at `model` by ONE wavefront,
+// every sum in list order. 64 points at a time: each lane evaluates one point and stores its 28 products product-major into the
+// wavefront's own LDS rows (28 stores to consecutive words: conflict-free); then lane k < 28 walks row k — 16 ds_read_b128 + 64 dependent
+// v_add_f32, nothing else: the chain of additions the reference's loop performs for sum k. Row stride 68 words: lane k starts at bank
+// 4k mod 64, so the 16 lanes of each ds_read_b128 group hit 16 disjoint bank quads. No barrier, no second wavefront to wait for.
+// Software pipeline over the groups g of 64 points (the loop is a chain of memory round trips otherwise — records, then the taps whose
+// addresses depend on them — with nothing else in this wavefront to cover them):
+//     warp(g + 1) + its tap requests | record requests of g + 2 | products(g) -> LDS | the 28 chains over group g
+// Returns the sums (lane k = sum k); *n_inside = the number of inside points (wavefront-uniform).
 template <bool HUBER, class Src>
-__device__ void ref_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* buf, RefShared& s, int dst, float* residuals = nullptr) {
-    constexpr int RS = RefRow<HUBER>::RS;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nchunks = (n + REF_CH - 1) / REF_CH;
-    int sa, sb, sw;
-    ref_lane_slots<HUBER>(lane, &sa, &sb, &sw);
+__device__ __forceinline__ float refw_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* lds, int* n_inside,
+                                           float* residuals = nullptr) {
+    const int lane = threadIdx.x & 63;
     float acc = 0.f;
     int cnt = 0;
-    if (threadIdx.x == 0) s.cnt = 0;
-    for (int ch = 0; ch <= nchunks; ++ch) {
-        if (wave != 0) {
-            if (ch < nchunks) {  // produce chunk ch
-                float* rows = buf + (ch & 1) * (REF_CH * RS);
-                const int p = (int)threadIdx.x - 64;
+    *n_inside = 0;
+    if (n <= 0) return acc;
+    REFW_T0(t_begin);
+    const int ngroups = (n + 63) >> 6;
+    typename Src::Raw raw_cur = src.load(min(lane, n - 1)), raw_nxt = raw_cur, raw_ahead = raw_cur;
+    RefTap tap_a, tap_b;
+    {
+        V3 P;
+        bool valid;
+        src.point(raw_cur, &P, &valid);
+        tap_a = refw_warp(P, valid && lane < n, c, model);
+    }
+    tap_b = tap_a;
+    raw_ahead = src.load(min(64 + lane, n - 1));
+    // one group; the taps alternate between two register sets (tap_cur is read, tap_nxt is requested) so that no register move stands between
+    // a request and its use a whole group later — a move would wait for the data at the end of every trip
+    auto group = [&](int g, const RefTap& tap_cur, RefTap& tap_nxt) {
+        // warp(g + 1) and the record request of g + 2, UNCONDITIONALLY (indices clamped to the list, points beyond it marked invalid): with
+        // the same requests on every path the compiler's s_waitcnt counting stays exact — one wait per trip, here, for what the PREVIOUS trip
+        // requested; a conditional request costs a vmcnt(0) in front of the products of every group. The price is one idle warp at the end.
+        raw_nxt = refw_moved(raw_ahead);
+        {
+            V3 P;
+            bool valid;
+            src.point(raw_nxt, &P, &valid);
+            tap_nxt = refw_warp(P, valid && (g + 1) * 64 + lane < n, c, model);
+        }
+        raw_ahead = src.load(min((g + 2) * 64 + lane, n - 1));
+        {  // products(g)
+            float J[6], tmpl, pr[RW_NSUM], res;
+            src.jac(raw_cur, J, &tmpl);
+            refw_products<HUBER>(tap_cur, tmpl, J, c.huber, pr, residuals ? &res : nullptr);
+            if (residuals && g * 64 + lane < n) residuals[g * 64 + lane] = res;
+            cnt += __popcll(__ballot(tap_cur.inside));
 #pragma unroll
-                for (int g2 = 0; g2 < REF_G; ++g2) {
-                    const int li = p + g2 * REF_PROD, i = ch * REF_CH + li;
-                    if (i < n) {
-                        RefPt pt;
-                        src.get(i, pt);
-                        float res;
-                        const bool in = ref_point_row<HUBER>(pt, c, model, rows + li * RS, residuals ? &res : nullptr);
-                        if (residuals) residuals[i] = res;
-                        cnt += in ? 1 : 0;
-                    }
-                }
-            }
-        } else if (ch > 0 && lane < 32) {  // consume chunk ch - 1: the sequential sums, one lane per sum (the upper half-wavefront sits out: its LDS requests would cost the same again)
-            const float* rows = buf + ((ch - 1) & 1) * (REF_CH * RS);
-            const int m = min(REF_CH, n - (ch - 1) * REF_CH);
-            int i = 0;
-            for (; i + 8 <= m; i += 8) {
-                float va[8], vb[8], vw[8];
+            for (int k = 0; k < RW_NSUM; ++k) lds[k * RW_STRIDE + lane] = pr[k];
+        }
+        refw_lds_fence();
+        if (lane < RW_NSUM) {
+            const float4* row = reinterpret_cast<const float4*>(lds + lane * RW_STRIDE);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    va[j] = rows[(i + j) * RS + sa];
-                    vb[j] = rows[(i + j) * RS + sb];
-                    if (HUBER) vw[j] = rows[(i + j) * RS + sw];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float pr = va[j] * vb[j];
-                    if (HUBER) pr = vw[j] * pr;
-                    acc = acc + pr;
-                }
-            }
-            for (; i < m; ++i) {
-                float pr = rows[i * RS + sa] * rows[i * RS + sb];
-                if (HUBER) pr = rows[i * RS + sw] * pr;
-                acc = acc + pr;
+            for (int q = 0; q < 16; ++q) {
+                const float4 v4 = row[q];
+                acc = acc + v4.x;
+                acc = acc + v4.y;
+                acc = acc + v4.z;
+                acc = acc + v4.w;
             }
         }
-        __syncthreads();
+        refw_lds_fence();
+        raw_cur = raw_nxt;  // (already waited for by warp(g + 1))
+    };
+    for (int g = 0; g < ngroups; g += 2) {
+        group(g, tap_a, tap_b);
+        if (g + 1 < ngroups) group(g + 1, tap_b, tap_a);
     }
-    if (wave != 0 && cnt != 0) atomicAdd(&s.cnt, cnt);
-    if (wave == 0 && lane < 28) s.sums[dst][lane == 0 ? 0 : lane + 1] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) s.sums[dst][1] = (float)s.cnt;
-    __syncthreads();
+    *n_inside = cnt;
+    REFW_ADD(0, __builtin_readcyclecounter() - t_begin);
+    REFW_ADD(2, ngroups);
+    REFW_ADD(3, 1);
+    return acc;
 }
 
 __device__ __forceinline__ float ref_uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -268,45 +325,47 @@ __device__ __forceinline__ Iso ref_iso_uniform(const Iso& m) {
                Quat{ref_uniform_f(m.q.i), ref_uniform_f(m.q.j), ref_uniform_f(m.q.k), ref_uniform_f(m.q.w)}};
 }
 
-// step() (lm_optimizer.rs:123-136) by one lane on the kept state's sums.
-__device__ __forceinline__ void ref_step_lane0(RefShared& s, int cur, const Iso& model, float lm_coef) {
-    if (threadIdx.x == 0) {
-        const float* a = s.sums[cur];
-        float h[36], g[6];
-        for (int q = 0; q < 6; ++q) g[q] = a[2 + q];
-        int k = 8;
-        for (int q = 0; q < 6; ++q)
-            for (int r = q; r < 6; ++r) {
-                h[q * 6 + r] = a[k];
-                h[r * 6 + q] = a[k];
-                ++k;
-            }
-        Iso cand;
-        const bool ok = lm_step(h, g, model, lm_coef, &cand);
-        iso_store(cand, s.cand);
-        s.cand[7] = ok ? 1.0f : 0.0f;
-    }
-    __syncthreads();
+// step() (lm_optimizer.rs:123-136) on the kept state's sums (lane k of `kept` = sum k), by every lane alike: the result is uniform.
+__device__ __forceinline__ bool refw_step(float kept, const Iso& model, float lm_coef, Iso* cand) {
+    float h[36], g6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) g6[q] = refw_lane(kept, 1 + q);
+    int k = 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = q; r < 6; ++r) {
+            const float v = refw_lane(kept, k);
+            h[q * 6 + r] = v;
+            h[r * 6 + q] = v;
+            ++k;
+        }
+    Iso out;
+    const bool ok = lm_step(h, g6, model, lm_coef, &out);
+    *cand = ref_iso_uniform(out);
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
 }
 
 // optimizer::State::iterative_solve (optimizer.rs:57-70) with init / step / eval / stop_criterion of lm_optimizer.rs:113-192.
 template <bool HUBER, class Src>
-__device__ bool ref_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
-                                int* n_full_out, float* buf, RefShared& s) {
+__device__ bool refw_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
+                                 int* n_full_out, float* lds) {
     Iso cur_model = *model;
-    int cur = 0;
-    ref_eval<HUBER>(src, n, c, cur_model, buf, s, cur);  // init: lm_optimizer.rs:113-118
-    float cur_energy = ref_uniform_f(s.sums[cur][0] / s.sums[cur][1]);  // energy_sum / residuals.len(): 0 / 0 = NaN like the reference
+    int cnt;
+    float kept = refw_eval<HUBER>(src, n, c, cur_model, lds, &cnt);  // init: lm_optimizer.rs:113-118
+    float cur_energy = refw_lane(kept, 0) / (float)cnt;              // energy_sum / residuals.len(): 0 / 0 = NaN like the reference
     float lm_coef = 0.1f;
     int nb_iter = 0, n_full = 1;
     for (;;) {
         nb_iter += 1;
-        ref_step_lane0(s, cur, cur_model, lm_coef);
-        if (ref_uniform_f(s.cand[7]) == 0.0f) return false;
-        const Iso cand = ref_iso_uniform(iso_load(s.cand));
+        Iso cand;
+        REFW_T0(t_step);
+        const bool step_ok = refw_step(kept, cur_model, lm_coef, &cand);
+        REFW_ADD(1, __builtin_readcyclecounter() - t_step);
+        if (!step_ok) return false;
         const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
-        ref_eval<HUBER>(src, n, c, cand, buf, s, 1 - cur);  // eval(): lm_optimizer.rs:140-149
-        const float energy = ref_uniform_f(s.sums[1 - cur][0] / s.sums[1 - cur][1]);
+        const float acc = refw_eval<HUBER>(src, n, c, cand, lds, &cnt);  // eval(): lm_optimizer.rs:140-149
+        const float energy = refw_lane(acc, 0) / (float)cnt;
         if (energy > cur_energy) {  // Err(energy)
             if (too_many_iterations) break;
             lm_coef *= 10.0f;
@@ -314,7 +373,7 @@ __device__ bool ref_solve_level(const Src& src, int n, const RefImg& c, Iso* mod
         }
         const float d_energy = cur_energy - energy;
         n_full += 1;
-        cur = 1 - cur;
+        kept = acc;
         cur_energy = energy;
         cur_model = cand;
         if (too_many_iterations) break;
@@ -352,18 +411,21 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
     }
 }
 
-// Tracker::track for a batch (inverse_compositional.rs:177-224): one workgroup per frame pair, all levels.
+// Tracker::track for a batch (inverse_compositional.rs:177-224): one WAVEFRONT per frame pair, all levels; the wavefronts of a
+// workgroup share nothing but the LDS allocation.
 template <bool HUBER, bool DENSE>
-__global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
-                                                                 const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
-                                                                 const uint16_t* __restrict__ kf_depth, Records rec,
-                                                                 const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
-                                                                 float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
-                                                                 vors_pair_stats* __restrict__ out_stats) {
-    constexpr int RS = RefRow<HUBER>::RS;
-    __shared__ __attribute__((aligned(16))) float buf[2 * REF_CH * RS];
-    __shared__ RefShared s;
-    const int pair = blockIdx.x;
+__global__ __launch_bounds__(64 * RW_WPB) void lm_ref_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                                   const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                   const uint16_t* __restrict__ kf_depth, Records rec,
+                                                                   const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
+                                                                   float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
+                                                                   vors_pair_stats* __restrict__ out_stats, int n_pairs) {
+    __shared__ __attribute__((aligned(16))) float lds_all[RW_WPB * RW_WORDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (pair >= n_pairs) return;
+    float* lds = lds_all + wave * RW_WORDS;
+    REFW_T0(t_kernel);
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
@@ -374,16 +436,16 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const u
         float energy = 0.f, lm_coef = 0.f;
         bool ok = false;
         ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
-            ok = ref_solve_level<HUBER>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, buf, s);
+            ok = refw_solve_level<HUBER>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
         });
-        if (out_stats && threadIdx.x == 0) {
+        if (out_stats && lane == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
             out_stats[pair].nb_grad_evals[lvl] = ok ? n_full : 0;
             out_stats[pair].energy[lvl] = ok ? energy : 0.f;
         }
         if (!ok) {
             went_well = false;
-            if (out_stats && threadIdx.x == 0)
+            if (out_stats && lane == 0)
                 for (int l2 = lvl - 1; l2 >= 0; --l2) {
                     out_stats[pair].nb_iter[l2] = 0;
                     out_stats[pair].nb_grad_evals[l2] = 0;
@@ -392,39 +454,40 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const u
             break;
         }
     }
-    // keyframe test on the coarsest level (inverse_compositional.rs:211-224): mean L1 displacement, summed in list order
+    // keyframe test on the coarsest level (inverse_compositional.rs:211-224): mean L1 displacement, summed in list order (every lane runs
+    // the same chain over the 64 displacements its wavefront just left in LDS)
     float flow_sum = 0.f;
     int flow_n = 0;
     {
         const int lvl = g.L - 1;
         const Intr k = g.lv[lvl].k;
-        __syncthreads();
         ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
-            constexpr int CAP = 2 * REF_CH * RS;
-            for (int base = 0; base < n; base += CAP) {
-                const int m = min(CAP, n - base);
-                for (int j = threadIdx.x; j < m; j += REF_BLOCK) {
-                    float x, y, iz;
-                    bool valid;
-                    src.xy_iz(base + j, &x, &y, &iz, &valid);
-                    float u, v;
-                    project_uv(k, iso_transform_point(lm_model, back_project(k, x, y, 1.0f / iz)), &u, &v);  // warp: lm_optimizer.rs:213-219
-                    buf[j] = valid ? fabsf(x - u) + fabsf(y - v) : -1.0f;  // (a displacement is never negative: -1 = not a candidate)
-                }
-                __syncthreads();
-                if (threadIdx.x == 0)
-                    for (int j = 0; j < m; ++j) {
-                        const float f = buf[j];
-                        if (!(f < 0.f)) {  // (NaN counts as a candidate, like the reference)
-                            flow_sum = flow_sum + f;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                float x, y, iz;
+                bool valid;
+                src.xy_iz(min(i, n - 1), &x, &y, &iz, &valid);
+                float u, v;
+                project_uv(k, iso_transform_point(lm_model, back_project(k, x, y, 1.0f / iz)), &u, &v);  // warp: lm_optimizer.rs:213-219
+                lds[lane] = (valid && i < n) ? fabsf(x - u) + fabsf(y - v) : -1.0f;  // (a displacement is never negative: -1 = not a candidate)
+                refw_lds_fence();
+                const float4* row = reinterpret_cast<const float4*>(lds);
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const float4 v4 = row[q];
+                    const float f4[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(f4[j] < 0.f)) {  // (NaN counts as a candidate, like the reference)
+                            flow_sum = flow_sum + f4[j];
                             flow_n += 1;
                         }
-                    }
-                __syncthreads();
+                }
+                refw_lds_fence();
             }
         });
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         const float optical_flow = flow_sum / (float)flow_n;
         const Iso pose = went_well ? iso_mul(kf_pose, iso_inverse(lm_model)) : prev_pose;  // inverse_compositional.rs:206-208
         iso_store(pose, out_poses7 + 7 * pair);
@@ -435,15 +498,14 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const u
             out_stats[pair].change_keyframe = (optical_flow >= 1.0f) ? 1 : 0;
         }
     }
+    REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
+    REFW_ADD(5, 1);
     if (out_stats) {  // usable candidates per level (diagnostics)
         for (int lvl = 0; lvl < g.L; ++lvl) {
             if constexpr (DENSE) {
-                __syncthreads();
-                if (threadIdx.x == 0) s.cnt = 0;
-                __syncthreads();
                 int mine = 0;
                 ref_with_source<true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
-                    for (int i = threadIdx.x; i < n; i += REF_BLOCK) {
+                    for (int i = lane; i < n; i += 64) {
                         int x, y;
                         float iz;
                         bool valid;
@@ -451,14 +513,14 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const u
                         mine += valid ? 1 : 0;
                     }
                 });
-                if (mine) atomicAdd(&s.cnt, mine);
-                __syncthreads();
-                if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = s.cnt;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
+                if (lane == 0) out_stats[pair].n_points[lvl] = mine;
             } else {
-                if (threadIdx.x == 0) out_stats[pair].n_points[lvl] = rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
+                if (lane == 0) out_stats[pair].n_points[lvl] = rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl];
             }
         }
-        if (threadIdx.x == 0)
+        if (lane == 0)
             for (int lvl = g.L; lvl < VORS_MAX_LEVELS; ++lvl) {
                 out_stats[pair].nb_iter[lvl] = 0;
                 out_stats[pair].nb_grad_evals[lvl] = 0;
@@ -468,11 +530,23 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_track_kernel(Geom g, const u
     }
 }
 
+// Wavefronts per workgroup: a large batch packs four pairs into a workgroup (fewer, fuller workgroups); a small one spreads its pairs
+// over the CUs one wavefront each. VORS_REF_WPB overrides (1, 2 or 4).
+static int refw_waves_per_block(int n_pairs) {
+    int wpb = n_pairs >= 2048 ? RW_WPB : (n_pairs >= 1024 ? 2 : 1);
+    if (const char* e = getenv("VORS_REF_WPB")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) wpb = v;
+    }
+    return wpb;
+}
+
 void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs,
                                hipStream_t s) {
-#define VORS_REF_ARGS dim3(n_pairs), dim3(REF_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, kf_poses7, \
-                      out_poses7, out_status, out_stats
+    const int wpb = refw_waves_per_block(n_pairs);
+#define VORS_REF_ARGS dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
+                      kf_poses7, out_poses7, out_status, out_stats, n_pairs
     const bool dense = g.mode == VORS_CANDIDATES_DENSE, huber = g.huber_delta > 0.f;
     if (dense && huber) hipLaunchKernelGGL((lm_ref_track_kernel<true, true>), VORS_REF_ARGS);
     else if (dense) hipLaunchKernelGGL((lm_ref_track_kernel<false, true>), VORS_REF_ARGS);
@@ -481,23 +555,45 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
 #undef VORS_REF_ARGS
 }
 
+#ifdef VORS_REFW_TIMING
+}  // namespace vors
+extern "C" int vors_debug_refw_profile(unsigned long long out[8], int reset) {  // development build only
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vors::refw_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vors::refw_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace vors {
+#endif
+
+// sums of one wavefront (lane k = sum k) + the inside count -> the 29-float layout of the C ABI: [0] = sum r^2, [1] = n_inside,
+// [2..7] = g, [8..28] = H upper triangle row-wise
+__device__ __forceinline__ void refw_store29(float acc, int cnt, float* out29) {
+    const int lane = threadIdx.x & 63;
+    if (lane < RW_NSUM) out29[lane == 0 ? 0 : lane + 1] = acc;
+    if (lane == 0) out29[1] = (float)cnt;
+}
+
 // One evaluation of one level of one pair of a prepared batch (vors_batch_eval_level in the REFERENCE arithmetic) -> 29 sums.
 template <bool HUBER, bool DENSE>
-__global__ __launch_bounds__(REF_BLOCK) void lm_ref_eval_level_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
-                                                                      const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
-                                                                      const uint16_t* __restrict__ kf_depth, Records rec, int pair, int lvl,
-                                                                      const float* __restrict__ model7, float* __restrict__ out29) {
-    constexpr int RS = RefRow<HUBER>::RS;
-    __shared__ __attribute__((aligned(16))) float buf[2 * REF_CH * RS];
-    __shared__ RefShared s;
+__global__ __launch_bounds__(64) void lm_ref_eval_level_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                               const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                               const uint16_t* __restrict__ kf_depth, Records rec, int pair, int lvl,
+                                                               const float* __restrict__ model7, float* __restrict__ out29) {
+    __shared__ __attribute__((aligned(16))) float lds[RW_WORDS];
     const Iso model = ref_iso_uniform(iso_load(model7));
     const RefImg c = ref_level_img(g, cur0, curu, pair, lvl);
-    ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) { ref_eval<HUBER>(src, n, c, model, buf, s, 0); });
-    if (threadIdx.x < 29) out29[threadIdx.x] = s.sums[0][threadIdx.x];
+    ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+        int cnt;
+        const float acc = refw_eval<HUBER>(src, n, c, model, lds, &cnt);
+        refw_store29(acc, cnt, out29);
+    });
 }
 void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
                                     const float* model7, float* out29, hipStream_t s) {
-#define VORS_REF_ARGS dim3(1), dim3(REF_BLOCK), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29
+#define VORS_REF_ARGS dim3(1), dim3(64), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29
     const bool dense = g.mode == VORS_CANDIDATES_DENSE, huber = g.huber_delta > 0.f;
     if (dense && huber) hipLaunchKernelGGL((lm_ref_eval_level_kernel<true, true>), VORS_REF_ARGS);
     else if (dense) hipLaunchKernelGGL((lm_ref_eval_level_kernel<false, true>), VORS_REF_ARGS);
@@ -508,15 +604,18 @@ void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, cons
 
 // ---- operator level on explicit observations, sums in the order of the observations (the reference's eval on that Obs) --------------
 template <bool HUBER>
-__global__ __launch_bounds__(REF_BLOCK) void lm_ref_eval_obs_kernel(RefObsSrc src, int n, RefImg c, const float* __restrict__ model7,
-                                                                    float* __restrict__ out, float* __restrict__ residuals) {
-    constexpr int RS = RefRow<HUBER>::RS;
-    __shared__ __attribute__((aligned(16))) float buf[2 * REF_CH * RS];
-    __shared__ RefShared s;
+__global__ __launch_bounds__(64) void lm_ref_eval_obs_kernel(RefObsSrc src, int n, RefImg c, const float* __restrict__ model7,
+                                                             float* __restrict__ out, float* __restrict__ residuals) {
+    __shared__ __attribute__((aligned(16))) float lds[RW_WORDS];
     const Iso model = ref_iso_uniform(iso_load(model7));
-    ref_eval<HUBER>(src, n, c, model, buf, s, 0, residuals);
+    int cnt;
+    const float acc = refw_eval<HUBER>(src, n, c, model, lds, &cnt, residuals);
+    float a[29];
+    a[0] = refw_lane(acc, 0);
+    a[1] = (float)cnt;
+#pragma unroll
+    for (int k = 1; k < RW_NSUM; ++k) a[k + 1] = refw_lane(acc, k);
     if (threadIdx.x == 0) {
-        const float* a = s.sums[0];
         out[0] = a[0] / a[1];
         out[1] = a[1];
         for (int q = 0; q < 6; ++q) out[2 + q] = a[2 + q];
@@ -530,15 +629,13 @@ __global__ __launch_bounds__(REF_BLOCK) void lm_ref_eval_obs_kernel(RefObsSrc sr
     }
 }
 template <bool HUBER>
-__global__ __launch_bounds__(REF_BLOCK) void lm_ref_solve_obs_kernel(RefObsSrc src, int n, RefImg c, const float* __restrict__ model7,
-                                                                     float* __restrict__ out) {
-    constexpr int RS = RefRow<HUBER>::RS;
-    __shared__ __attribute__((aligned(16))) float buf[2 * REF_CH * RS];
-    __shared__ RefShared s;
+__global__ __launch_bounds__(64) void lm_ref_solve_obs_kernel(RefObsSrc src, int n, RefImg c, const float* __restrict__ model7,
+                                                              float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[RW_WORDS];
     Iso model = ref_iso_uniform(iso_load(model7));
     int nb_iter = 0, n_full = 0;
     float energy = 0.f, lm_coef = 0.f;
-    const bool ok = ref_solve_level<HUBER>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, buf, s);
+    const bool ok = refw_solve_level<HUBER>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, lds);
     if (threadIdx.x == 0) {
         iso_store(model, out);
         out[7] = (float)nb_iter;
@@ -551,15 +648,15 @@ void launch_lm_eval_obs_reference(Intr k, int rows, int cols, const uint8_t* ima
                                   float* out, float* residuals, hipStream_t s) {
     const RefObsSrc src{rec.A, rec.B, rec.C};
     const RefImg c{image, rows, cols, k, huber_delta};
-    if (huber_delta > 0.f) hipLaunchKernelGGL(lm_ref_eval_obs_kernel<true>, dim3(1), dim3(REF_BLOCK), 0, s, src, n, c, model7, out, residuals);
-    else hipLaunchKernelGGL(lm_ref_eval_obs_kernel<false>, dim3(1), dim3(REF_BLOCK), 0, s, src, n, c, model7, out, residuals);
+    if (huber_delta > 0.f) hipLaunchKernelGGL(lm_ref_eval_obs_kernel<true>, dim3(1), dim3(64), 0, s, src, n, c, model7, out, residuals);
+    else hipLaunchKernelGGL(lm_ref_eval_obs_kernel<false>, dim3(1), dim3(64), 0, s, src, n, c, model7, out, residuals);
 }
 void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* image, int n, Records rec, float huber_delta, const float* model7,
                                    float* out, hipStream_t s) {
     const RefObsSrc src{rec.A, rec.B, rec.C};
     const RefImg c{image, rows, cols, k, huber_delta};
-    if (huber_delta > 0.f) hipLaunchKernelGGL(lm_ref_solve_obs_kernel<true>, dim3(1), dim3(REF_BLOCK), 0, s, src, n, c, model7, out);
-    else hipLaunchKernelGGL(lm_ref_solve_obs_kernel<false>, dim3(1), dim3(REF_BLOCK), 0, s, src, n, c, model7, out);
+    if (huber_delta > 0.f) hipLaunchKernelGGL(lm_ref_solve_obs_kernel<true>, dim3(1), dim3(64), 0, s, src, n, c, model7, out);
+    else hipLaunchKernelGGL(lm_ref_solve_obs_kernel<false>, dim3(1), dim3(64), 0, s, src, n, c, model7, out);
 }
 
 // ------------------------------------------------------------------------------------------------------------
