@@ -181,6 +181,9 @@ static void batch_free(vors_batch* b) {
     if (b->split.ev_join) (void)hipEventDestroy(b->split.ev_join);
     if (b->split.side_list) (void)hipFree(b->split.side_list);
     if (b->split.join_list) (void)hipFree(b->split.join_list);
+    void* planes[] = {b->rec.dense_t.kf0, b->rec.dense_t.kfu, b->rec.dense_t.cur0, b->rec.dense_t.curu, b->rec.dense_t.depth, b->rec.dense_t.iz};
+    for (void* p : planes)
+        if (p) (void)hipFree(p);
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state, b->dso.pick_list,
                      b->mask0, b->pp.iz, b->pp.v, b->pp.counts, b->rec.n_used, b->rec.S, b->rec.stage, b->rec.region_cnt,
                      b->split.state, b->split.partials, b->split.list[0], b->split.list[1], b->split.count};
@@ -318,6 +321,15 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.V, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
+        if (g.arith == VORS_ARITH_REFERENCE) {  // column-major copies of what the LM kernel reads (engine.h RefDensePlanes)
+            RefDensePlanes& t = b->rec.dense_t;
+            if (e == hipSuccess) e = dmalloc(&t.kf0, np * g.S0, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.kfu, np * g.upper_stride, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.cur0, np * g.S0, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.curu, np * g.upper_stride, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.depth, np * g.S0, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.iz, slots, &b->bytes);
+        }
     } else {  // sparse modes: compact 12-byte candidate lists (+ the keyframe kernel's staging grid in coarse-to-fine mode)
         if (e == hipSuccess) e = dmalloc(&b->rec.S, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
@@ -527,7 +539,10 @@ vors_status vors_batch_prepare_keyframes(vors_batch* b, int n_pairs, const uint8
     } else {
         launch_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
     }
-    if (b->g.arith == VORS_ARITH_REFERENCE) launch_sort_colmajor(b->g, b->rec, n_pairs, s);  // extract_z's order (inverse_compositional.rs:260-279)
+    if (b->g.arith == VORS_ARITH_REFERENCE) {  // extract_z's order (inverse_compositional.rs:260-279): sorted lists / column-major planes
+        launch_sort_colmajor(b->g, b->rec, n_pairs, s);
+        launch_ref_dense_planes_keyframe(b->g, kf, d_kf_depth, b->rec, n_pairs, s);
+    }
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;
@@ -545,6 +560,7 @@ static vors_status batch_track_current(vors_batch* b, int n_pairs, const uint8_t
     Pyramid cur{d_cur_gray, b->cur_upper};
     STAGE_BEGIN(b, 2, s);
     launch_pyramid(b->g, cur, n_pairs, s);
+    if (b->g.arith == VORS_ARITH_REFERENCE) launch_ref_dense_planes_current(b->g, cur, b->rec, n_pairs, s);
     STAGE_END(b, 2, s);
     STAGE_BEGIN(b, 3, s);
     if (b->g.arith == VORS_ARITH_REFERENCE)
@@ -1270,7 +1286,11 @@ static vors_status trackers_promote(vors_trackers* t, const uint8_t* d_gray, con
     } else {
         launch_keyframe(gm, Pyramid{d_gray, b->cur_upper}, d_depth, b->rec, n, s);
     }
-    if (b->g.arith == VORS_ARITH_REFERENCE) launch_sort_colmajor(gm, b->rec, n, s);
+    if (b->g.arith == VORS_ARITH_REFERENCE) {
+        launch_sort_colmajor(gm, b->rec, n, s);
+        if (b->g.mode == VORS_CANDIDATES_DENSE)
+            launch_ref_dense_planes_keyframe(gm, Pyramid{t->own_gray.as<uint8_t>(), b->kf_upper}, t->own_depth.as<uint16_t>(), b->rec, n, s);
+    }
     STAGE_END(b, 1, s);
     HIP_TRY(hipGetLastError());
     return VORS_OK;

@@ -66,6 +66,20 @@ __host__ __device__ inline int slim_gy(uint32_t tg) { return ((int)(tg << 4)) >>
 //   B = (J0, J1, J2, J3) C = (J4, J5)   warp Jacobian (inverse_compositional.rs:313-341)
 //   XY = x | y << 16     pixel coordinates (keyframe test, inspection)
 //   IZ = inverse depth   (inspection only)
+// REFERENCE arithmetic, dense mode: COLUMN-MAJOR copies of everything the LM kernel reads. The reference enumerates the pixels of a level
+// column by column (DMatrix order, inverse_compositional.rs:260-279), so consecutive points of its order are consecutive ROWS: on the
+// row-major planes a wavefront's 64 points touch 64 cache lines per load, on these they touch one or two — and point i of the enumeration
+// is element i of the plane. Laid out like the originals (level 0: pair stride S0; upper levels: pair stride upper_stride, level offset
+// img_off; inverse depths of levels >= 1: pair stride slots_total, level offset slot_off), every level transposed within its own slot.
+struct RefDensePlanes {
+    uint8_t* kf0;      // keyframe level 0
+    uint8_t* kfu;      // keyframe levels >= 1
+    uint8_t* cur0;     // current frame level 0
+    uint8_t* curu;     // current frame levels >= 1
+    uint16_t* depth;   // keyframe depth map (level 0)
+    float* iz;         // inverse depths of levels >= 1 (NaN = Unknown)
+};
+
 struct Records {
     float4* A;
     float4* B;
@@ -81,6 +95,7 @@ struct Records {
     int* region_cnt;    // coarse-to-fine mode: [pair][level][region] points per wavefront region
     int n_regions;      //   regions per level (= wavefronts of the keyframe kernel per pair)
     int kf_r;           //   roots per wavefront region
+    RefDensePlanes dense_t;  // REFERENCE arithmetic, dense mode (all null otherwise)
     SlimRec* sort_tmp;  // REFERENCE arithmetic, sparse modes: scratch of the column-major sort (lm_reference.hip), laid out like S; the
                         // coarse-to-fine mode lends its staging grid, which is free once the regions have been compacted
 };
@@ -196,6 +211,10 @@ void launch_lm_track_fused(const Geom& g, Pyramid cur, Pyramid kf, const uint16_
 // REFERENCE arithmetic (lm_reference.hip): the candidate lists of n_pairs pairs into extract_z's column-major order (no-op in dense mode;
 // honours Geom::sel_list), and the tracker with the reference's sequential sums.
 void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s);
+// dense mode: the column-major planes of the keyframe side (pyramid, depth map, inverse depths of levels >= 1; honours Geom::sel_list) and
+// of the current frame's pyramid -> rec.dense_t
+void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
+void launch_ref_dense_planes_current(const Geom& g, Pyramid cur, Records rec, int n_pairs, hipStream_t s);
 void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs, hipStream_t s);
 void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,

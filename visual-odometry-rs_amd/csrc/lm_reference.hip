@@ -56,6 +56,7 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
     const SlimRec* S;
     Intr k;
     FastDiv fu, fv;  // the focal lengths as verified fast divisors (lie.h div_uniform: bit-identical to the IEEE quotient, or `ok` = 0)
+    static constexpr bool kTransposed = false;  // the current image is row-major
     typedef SlimRec Raw;
     __device__ __forceinline__ Raw load(int i) const { return S[(unsigned)i]; }
     __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
@@ -74,7 +75,9 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
         *valid = true;
     }
 };
-struct RefDenseSrc {  // dense mode: pixel i of the column-major enumeration, recomputed from the keyframe pyramid + depth / IZ plane
+struct RefDenseSrc {  // dense mode on the ROW-MAJOR planes (vors_batch_eval_level with the REFERENCE arithmetic on a handle of another
+                      // arithmetic: no column-major planes there): pixel i of the column-major enumeration, gathered
+    static constexpr bool kTransposed = false;
     const Geom* g;
     const uint8_t* kf0;
     const uint8_t* kfu;
@@ -124,7 +127,80 @@ struct RefDenseSrc {  // dense mode: pixel i of the column-major enumeration, re
         *y = (float)yi;
     }
 };
+// Dense mode on the COLUMN-MAJOR planes (engine.h RefDensePlanes): pixel i of the enumeration is element i of every plane of the level.
+struct RefDenseTSrc {
+    static constexpr bool kTransposed = true;  // the current image is column-major as well
+    const uint8_t* kf;       // this level of the keyframe pyramid, column-major (level 0: gradient + template)
+    const uint8_t* kf_fine;  // the next finer level (levels >= 1: block gradient + template, gradient.rs:74-93)
+    const uint16_t* depth;   // level 0
+    const float* iz;         // levels >= 1, NaN = Unknown
+    float depth_scale;
+    int lvl, rows, cols, fine_rows;
+    uint32_t magic;          // floor(2^32 / rows) + 1: i / rows == __umulhi(i, magic) for i * rows < 2^32 (i < 2^21, rows <= 2^11)
+    Intr k;
+    struct Raw {
+        uint32_t xy;   // x | y << 16
+        float iz;      // inverse depth (anything when !valid)
+        uint32_t tgv;  // slim_pack_tg(template, gx, gy) | valid << 31
+    };
+    __device__ __forceinline__ void coords(int i, int* x, int* y) const {
+        const int xx = (int)__umulhi((unsigned)i, magic);
+        *x = xx;
+        *y = i - xx * rows;
+    }
+    __device__ __forceinline__ void raw(int i, int* x, int* y, float* izv, bool* valid) const {
+        coords(i, x, y);
+        if (lvl == 0) {
+            const int dz = depth[(unsigned)i];
+            *valid = dz != 0;
+            *izv = depth_scale / (float)dz;  // inverse_depth.rs:24-29
+        } else {
+            const float z = iz[(unsigned)i];
+            *valid = !(z != z);
+            *izv = z;
+        }
+    }
+    __device__ __forceinline__ Raw load(int i) const {
+        int x, y, gx, gy, tm;
+        float izv;
+        bool valid;
+        raw(i, &x, &y, &izv, &valid);
+        if (lvl == 0) {  // centred difference, truncating / 2, 1-px border = 0 (gradient.rs:15-33); neighbours in x are `rows` bytes apart
+            const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
+            const unsigned o = (unsigned)i, dx = interior ? (unsigned)rows : 0u, dy = interior ? 1u : 0u;
+            const int l0 = kf[o - dx], r0 = kf[o + dx], u0 = kf[o - dy], d0 = kf[o + dy];
+            tm = kf[o];
+            gx = (r0 - l0) / 2;
+            gy = (d0 - u0) / 2;
+        } else {  // 2x2 block of the finer level: a = (2y, 2x), b = (2y + 1, 2x), c = (2y, 2x + 1), d = (2y + 1, 2x + 1): a | b and c | d are adjacent
+            const unsigned o = __umul24((unsigned)(2 * x), (unsigned)fine_rows) + (unsigned)(2 * y);
+            uint16_t r0, r1;
+            __builtin_memcpy(&r0, kf_fine + o, 2);
+            __builtin_memcpy(&r1, kf_fine + (o + (unsigned)fine_rows), 2);
+            const int a = r0 & 0xff, b = r0 >> 8, c2 = r1 & 0xff, d = r1 >> 8;
+            gx = (c2 + d - a - b) / 2;
+            gy = (b - a + d - c2) / 2;
+            tm = (a + b + c2 + d) >> 2;  // = the level's own pixel (multires.rs:21-31)
+        }
+        return Raw{(uint32_t)x | ((uint32_t)y << 16), izv, slim_pack_tg(tm, gx, gy) | (valid ? 0x80000000u : 0u)};
+    }
+    __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
+        *P = back_project(k, (float)(r.xy & 0xffffu), (float)(r.xy >> 16), 1.0f / r.iz);
+        *valid = (r.tgv >> 31) != 0u;
+    }
+    __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
+        *tmpl = (float)(r.tgv & 0xffu);
+        warp_jacobian_at((float)slim_gx(r.tgv), (float)slim_gy(r.tgv), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, k, J);
+    }
+    __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* izv, bool* valid) const {
+        int xi, yi;
+        raw(i, &xi, &yi, izv, valid);
+        *x = (float)xi;
+        *y = (float)yi;
+    }
+};
 struct RefObsSrc {  // operator level: explicit observations in the caller's order (Obs, lm_optimizer.rs:43-58)
+    static constexpr bool kTransposed = false;
     const float4* A;
     const float4* B;
     const float2* C;
@@ -147,19 +223,21 @@ struct RefObsSrc {  // operator level: explicit observations in the caller's ord
 // two 16-bit loads (left | right << 8 of the upper and of the lower row).
 struct RefTap {
     float fa, fb;     // u - floor(u), v - floor(v)
-    uint32_t t0, t1;  // taps of row floor(v) and of the row below
+    uint32_t t0, t1;  // row-major image: taps of row floor(v) and of the row below; column-major: of column floor(u) and of the next one
     bool inside;
 };
+template <bool TR>
 __device__ __forceinline__ RefTap refw_warp(const V3& P, bool valid, const RefImg& c, const Iso& model) {
     float u, v;
     project_uv(c.k, iso_transform_point(model, P), &u, &v);
     const float uf = floorf(u), vf = floorf(v);
     RefTap t;
     t.inside = valid && (uf >= 0.f) && (uf < (float)(c.cols - 2)) && (vf >= 0.f) && (vf < (float)(c.rows - 2));
-    const unsigned off = t.inside ? (unsigned)((int)vf * c.cols + (int)uf) : 0u;
+    const unsigned pitch = (unsigned)(TR ? c.rows : c.cols);
+    const unsigned off = t.inside ? (TR ? (unsigned)((int)uf * c.rows + (int)vf) : (unsigned)((int)vf * c.cols + (int)uf)) : 0u;
     uint16_t a, b;
     __builtin_memcpy(&a, c.img + off, 2);
-    __builtin_memcpy(&b, c.img + (off + (unsigned)c.cols), 2);
+    __builtin_memcpy(&b, c.img + (off + pitch), 2);
     t.t0 = a;
     t.t1 = b;
     t.fa = u - uf;
@@ -171,10 +249,11 @@ __device__ __forceinline__ RefTap refw_warp(const V3& P, bool valid, const RefIm
 // `r * r` (lm_optimizer.rs:80), `jac * r` (lm_optimizer.rs:98) and `jac * jac^T` (inverse_compositional.rs:347); Huber extension: loss term,
 // jac * (w r), w * (jac * jac^T) like the oracle. An outside point contributes +0 to every sum (its residual and Jacobian are replaced by
 // +0, so every product is +0): adding +0 is exact (a running sum that starts at +0 never becomes -0), so it equals skipping the point.
-template <bool HUBER>
+template <bool HUBER, bool TR>
 __device__ __forceinline__ void refw_products(const RefTap& t, float tmpl, const float Jin[6], float huber, float pr[RW_NSUM], float* res_out) {
-    const float vu_00 = (float)(t.t0 & 0xffu), vu_01 = (float)(t.t0 >> 8);
-    const float vu_10 = (float)(t.t1 & 0xffu), vu_11 = (float)(t.t1 >> 8);
+    // vu_RC: row floor(v) + R, column floor(u) + C
+    const float vu_00 = (float)(t.t0 & 0xffu), vu_01 = (float)(TR ? t.t1 & 0xffu : t.t0 >> 8);
+    const float vu_10 = (float)(TR ? t.t0 >> 8 : t.t1 & 0xffu), vu_11 = (float)(t.t1 >> 8);
     const float fa = t.fa, fb = t.fb;
     const float im = (1.0f - fb) * (1.0f - fa) * vu_00 + fb * (1.0f - fa) * vu_10 + (1.0f - fb) * fa * vu_01 + fb * fa * vu_11;
     const float r_in = im - tmpl;
@@ -232,8 +311,37 @@ __device__ __forceinline__ T refw_moved(const T& v) {
     return out;
 }
 
+// The 28 chains over the 64 points of `nb` consecutive product blocks (`stride` words apart): lane k < 28 adds row k to its sum, point
+// after point — the reference's `energy_sum += ...`, `gradient += ...`, `hessian += ...` (lm_optimizer.rs:80,98-99) for these candidates.
+// The additions are one dependent chain (4.6 cycles each); the 16-byte row reads that feed it take ~130 cycles each, so WIN of them are
+// kept in flight (a rolling window of 4 WIN registers, running on into the next block; 8 where registers are free, 4 next to a producer): the chain never waits for LDS after the first read.
+template <int WIN>
+__device__ __forceinline__ void refw_consume(const float* block, int nb, int stride, float& acc) {
+    const int lane = threadIdx.x & 63;
+    if (lane < RW_NSUM) {
+        const float4* row = reinterpret_cast<const float4*>(block + lane * RW_STRIDE);
+        float4 w[WIN];
+#pragma unroll
+        for (int q = 0; q < WIN; ++q) w[q] = row[q];
+        for (int j = 0; j < nb; ++j) {
+            const float4* nxt = j + 1 < nb ? row + (stride >> 2) : row;  // (after the last block: WIN reads nobody uses)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 v4 = w[q % WIN];
+                w[q % WIN] = q + WIN < 16 ? row[q + WIN] : nxt[q + WIN - 16];
+                acc = acc + v4.x;
+                acc = acc + v4.y;
+                acc = acc + v4.z;
+                acc = acc + v4.w;
+            }
+            row = nxt;
+        }
+    }
+}
+
 #ifdef VORS_REFW_TIMING  // development build (tools/build_ref_variant.sh): shader cycles per phase, summed over all wavefronts
-__device__ unsigned long long refw_prof[8];  // 0 eval cycles, 1 step cycles, 2 groups of 64 points, 3 evaluations, 4 kernel cycles, 5 wavefronts
+__device__ unsigned long long refw_prof[8];  // 0 eval cycles (coop: wavefront 0 summing), 1 step cycles, 2 groups of 64 points (coop: barriers), 3 evaluations,
+                                             // 4 kernel cycles, 5 wavefronts, 6 coop: verdict + step + publish, 7 coop: wavefront 0 at barriers
 #define REFW_T0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define REFW_ADD(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&refw_prof[slot], (unsigned long long)(v)); } while (0)
 #else
@@ -266,7 +374,7 @@ __device__ __forceinline__ float refw_eval(const Src& src, int n, const RefImg& 
         V3 P;
         bool valid;
         src.point(raw_cur, &P, &valid);
-        tap_a = refw_warp(P, valid && lane < n, c, model);
+        tap_a = refw_warp<Src::kTransposed>(P, valid && lane < n, c, model);
     }
     tap_b = tap_a;
     raw_ahead = src.load(min(64 + lane, n - 1));
@@ -281,30 +389,20 @@ __device__ __forceinline__ float refw_eval(const Src& src, int n, const RefImg& 
             V3 P;
             bool valid;
             src.point(raw_nxt, &P, &valid);
-            tap_nxt = refw_warp(P, valid && (g + 1) * 64 + lane < n, c, model);
+            tap_nxt = refw_warp<Src::kTransposed>(P, valid && (g + 1) * 64 + lane < n, c, model);
         }
         raw_ahead = src.load(min((g + 2) * 64 + lane, n - 1));
         {  // products(g)
             float J[6], tmpl, pr[RW_NSUM], res;
             src.jac(raw_cur, J, &tmpl);
-            refw_products<HUBER>(tap_cur, tmpl, J, c.huber, pr, residuals ? &res : nullptr);
+            refw_products<HUBER, Src::kTransposed>(tap_cur, tmpl, J, c.huber, pr, residuals ? &res : nullptr);
             if (residuals && g * 64 + lane < n) residuals[g * 64 + lane] = res;
             cnt += __popcll(__ballot(tap_cur.inside));
 #pragma unroll
             for (int k = 0; k < RW_NSUM; ++k) lds[k * RW_STRIDE + lane] = pr[k];
         }
         refw_lds_fence();
-        if (lane < RW_NSUM) {
-            const float4* row = reinterpret_cast<const float4*>(lds + lane * RW_STRIDE);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 v4 = row[q];
-                acc = acc + v4.x;
-                acc = acc + v4.y;
-                acc = acc + v4.z;
-                acc = acc + v4.w;
-            }
-        }
+        refw_consume<4>(lds, 1, 0, acc);
         refw_lds_fence();
         raw_cur = raw_nxt;  // (already waited for by warp(g + 1))
     };
@@ -346,62 +444,105 @@ __device__ __forceinline__ bool refw_step(float kept, const Iso& model, float lm
     return __builtin_amdgcn_readfirstlane((int)ok) != 0;
 }
 
-// optimizer::State::iterative_solve (optimizer.rs:57-70) with init / step / eval / stop_criterion of lm_optimizer.rs:113-192.
+// optimizer::State::iterative_solve (optimizer.rs:57-70) with init / step / eval / stop_criterion of lm_optimizer.rs:113-192 as a state
+// machine driven by evaluations: whoever evaluates `cand` (one wavefront, or a workgroup of them) feeds the sums to ref_lm_advance and is
+// told what comes next. Everything is wavefront-uniform except `kept` (lane k = sum k of the kept state).
+enum { REF_LM_EVAL = 0, REF_LM_DONE = 1, REF_LM_FAIL = 2 };
+struct RefLm {
+    Iso cur_model;     // the kept state's model
+    Iso cand;          // model to evaluate next (REF_LM_EVAL)
+    float kept;        // sums of the kept state
+    float cur_energy, lm_coef;
+    int nb_iter, n_full;
+    bool started;      // the initial evaluation (init: lm_optimizer.rs:113-118) has been fed
+};
+__device__ __forceinline__ void ref_lm_begin(RefLm& s, const Iso& model) {
+    s.cur_model = model;
+    s.cand = model;
+    s.kept = 0.f;
+    s.cur_energy = 0.f;
+    s.lm_coef = 0.1f;
+    s.nb_iter = 0;
+    s.n_full = 0;
+    s.started = false;
+}
+// `acc` / `cnt`: sums and inside count of the evaluation of s.cand. Returns REF_LM_EVAL (evaluate s.cand next), REF_LM_DONE (the level's
+// result is s.cur_model) or REF_LM_FAIL (step() failed: "Error at Cholesky decomposition of hessian", lm_optimizer.rs:131-133).
+__device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt) {
+    const float energy = refw_lane(acc, 0) / (float)cnt;  // energy_sum / residuals.len(): 0 / 0 = NaN like the reference
+    if (!s.started) {  // init: lm_optimizer.rs:113-118
+        s.started = true;
+        s.kept = acc;
+        s.cur_energy = energy;
+        s.n_full = 1;
+    } else {  // eval() + stop_criterion: lm_optimizer.rs:140-192
+        const bool too_many_iterations = s.nb_iter > 20;
+        if (energy > s.cur_energy) {  // Err(energy)
+            if (too_many_iterations) return REF_LM_DONE;
+            s.lm_coef *= 10.0f;
+        } else {
+            const float d_energy = s.cur_energy - energy;
+            s.n_full += 1;
+            s.kept = acc;
+            s.cur_energy = energy;
+            s.cur_model = s.cand;
+            if (too_many_iterations) return REF_LM_DONE;
+            s.lm_coef = 0.1f * s.lm_coef;
+            if (!(d_energy > 1.0f)) return REF_LM_DONE;
+        }
+    }
+    s.nb_iter += 1;
+    REFW_T0(t_step);
+    const bool ok = refw_step(s.kept, s.cur_model, s.lm_coef, &s.cand);
+    REFW_ADD(1, __builtin_readcyclecounter() - t_step);
+    return ok ? REF_LM_EVAL : REF_LM_FAIL;
+}
+
+// One level by one wavefront.
 template <bool HUBER, class Src>
 __device__ bool refw_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
                                  int* n_full_out, float* lds) {
-    Iso cur_model = *model;
-    int cnt;
-    float kept = refw_eval<HUBER>(src, n, c, cur_model, lds, &cnt);  // init: lm_optimizer.rs:113-118
-    float cur_energy = refw_lane(kept, 0) / (float)cnt;              // energy_sum / residuals.len(): 0 / 0 = NaN like the reference
-    float lm_coef = 0.1f;
-    int nb_iter = 0, n_full = 1;
-    for (;;) {
-        nb_iter += 1;
-        Iso cand;
-        REFW_T0(t_step);
-        const bool step_ok = refw_step(kept, cur_model, lm_coef, &cand);
-        REFW_ADD(1, __builtin_readcyclecounter() - t_step);
-        if (!step_ok) return false;
-        const bool too_many_iterations = nb_iter > 20;  // stop_criterion: lm_optimizer.rs:156-192
-        const float acc = refw_eval<HUBER>(src, n, c, cand, lds, &cnt);  // eval(): lm_optimizer.rs:140-149
-        const float energy = refw_lane(acc, 0) / (float)cnt;
-        if (energy > cur_energy) {  // Err(energy)
-            if (too_many_iterations) break;
-            lm_coef *= 10.0f;
-            continue;
-        }
-        const float d_energy = cur_energy - energy;
-        n_full += 1;
-        kept = acc;
-        cur_energy = energy;
-        cur_model = cand;
-        if (too_many_iterations) break;
-        lm_coef = 0.1f * lm_coef;
-        if (!(d_energy > 1.0f)) break;
-    }
-    *model = cur_model;
-    *nb_iter_out = nb_iter;
-    *energy_out = cur_energy;
-    *lm_coef_out = lm_coef;
-    *n_full_out = n_full;
+    RefLm s;
+    ref_lm_begin(s, *model);
+    int cmd;
+    do {
+        int cnt;
+        const float acc = refw_eval<HUBER>(src, n, c, s.cand, lds, &cnt);
+        cmd = ref_lm_advance(s, acc, cnt);
+    } while (cmd == REF_LM_EVAL);
+    if (cmd == REF_LM_FAIL) return false;
+    *model = s.cur_model;
+    *nb_iter_out = s.nb_iter;
+    *energy_out = s.cur_energy;
+    *lm_coef_out = s.lm_coef;
+    *n_full_out = s.n_full;
     return true;
 }
 
-__device__ __forceinline__ RefImg ref_level_img(const Geom& g, const uint8_t* cur0, const uint8_t* curu, int pair, int lvl) {
+// Where the points of a level come from (template argument SRC of the kernels below).
+enum { REF_SRC_SLIM = 0, REF_SRC_DENSE_ROWMAJOR = 1, REF_SRC_DENSE_T = 2 };
+
+template <int SRC>
+__device__ __forceinline__ RefImg ref_level_img(const Geom& g, const uint8_t* cur0, const uint8_t* curu, const Records& rec, int pair, int lvl) {
     RefImg c;
-    c.img = level_ptr(g, cur0, curu, pair, lvl);
+    c.img = SRC == REF_SRC_DENSE_T ? level_ptr(g, rec.dense_t.cur0, rec.dense_t.curu, pair, lvl) : level_ptr(g, cur0, curu, pair, lvl);
     c.rows = g.lv[lvl].rows;
     c.cols = g.lv[lvl].cols;
     c.k = g.lv[lvl].k;
     c.huber = g.huber_delta;
     return c;
 }
-template <bool DENSE, class F>
+template <int SRC, class F>
 __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair, const uint8_t* kf0, const uint8_t* kfu, const uint16_t* kf_depth,
                                                 const Records& rec, F&& f) {
     const LevelGeom lg = g.lv[lvl];
-    if constexpr (DENSE) {
+    if constexpr (SRC == REF_SRC_DENSE_T) {
+        const RefDensePlanes& t = rec.dense_t;
+        RefDenseTSrc src{level_ptr(g, t.kf0, t.kfu, pair, lvl), lvl > 0 ? level_ptr(g, t.kf0, t.kfu, pair, lvl - 1) : nullptr,
+                         t.depth + (size_t)pair * g.S0, lvl > 0 ? t.iz + (size_t)pair * g.slots_total + lg.slot_off : nullptr, g.depth_scale,
+                         lvl, lg.rows, lg.cols, lvl > 0 ? g.lv[lvl - 1].rows : 0, 0xffffffffu / (unsigned)lg.rows + 1u, lg.k};
+        f(src, lg.rows * lg.cols);
+    } else if constexpr (SRC == REF_SRC_DENSE_ROWMAJOR) {
         RefDenseSrc src{&g, kf0, kfu, kf_depth + (size_t)pair * g.S0, lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr,
                         pair, lvl, lg.rows, lg.cols, lg.k};
         f(src, lg.rows * lg.cols);
@@ -411,49 +552,13 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
     }
 }
 
-// Tracker::track for a batch (inverse_compositional.rs:177-224): one WAVEFRONT per frame pair, all levels; the wavefronts of a
-// workgroup share nothing but the LDS allocation.
-template <bool HUBER, bool DENSE>
-__global__ __launch_bounds__(64 * RW_WPB) void lm_ref_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
-                                                                   const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
-                                                                   const uint16_t* __restrict__ kf_depth, Records rec,
-                                                                   const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
-                                                                   float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
-                                                                   vors_pair_stats* __restrict__ out_stats, int n_pairs) {
-    __shared__ __attribute__((aligned(16))) float lds_all[RW_WPB * RW_WORDS];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * (int)(blockDim.x >> 6) + wave;
-    if (pair >= n_pairs) return;
-    float* lds = lds_all + wave * RW_WORDS;
-    REFW_T0(t_kernel);
-    const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
-    const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
-    Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
-    bool went_well = true;
-    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
-        const RefImg c = ref_level_img(g, cur0, curu, pair, lvl);
-        int nb_iter = 0, n_full = 0;
-        float energy = 0.f, lm_coef = 0.f;
-        bool ok = false;
-        ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
-            ok = refw_solve_level<HUBER>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
-        });
-        if (out_stats && lane == 0) {
-            out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
-            out_stats[pair].nb_grad_evals[lvl] = ok ? n_full : 0;
-            out_stats[pair].energy[lvl] = ok ? energy : 0.f;
-        }
-        if (!ok) {
-            went_well = false;
-            if (out_stats && lane == 0)
-                for (int l2 = lvl - 1; l2 >= 0; --l2) {
-                    out_stats[pair].nb_iter[l2] = 0;
-                    out_stats[pair].nb_grad_evals[l2] = 0;
-                    out_stats[pair].energy[l2] = 0.f;
-                }
-            break;
-        }
-    }
+// The end of Tracker::track for one pair, by ONE wavefront (`lds`: at least 64 floats of its own): the keyframe test on the coarsest level
+// (inverse_compositional.rs:211-224), the pose (inverse_compositional.rs:206-208), the outputs.
+template <int SRC>
+__device__ __forceinline__ void ref_finish_pair(const Geom& g, int pair, const uint8_t* kf0, const uint8_t* kfu, const uint16_t* kf_depth,
+                                                const Records& rec, const Iso& lm_model, bool went_well, const Iso& prev_pose, const Iso& kf_pose,
+                                                float* lds, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats) {
+    const int lane = threadIdx.x & 63;
     // keyframe test on the coarsest level (inverse_compositional.rs:211-224): mean L1 displacement, summed in list order (every lane runs
     // the same chain over the 64 displacements its wavefront just left in LDS)
     float flow_sum = 0.f;
@@ -461,7 +566,7 @@ __global__ __launch_bounds__(64 * RW_WPB) void lm_ref_track_kernel(Geom g, const
     {
         const int lvl = g.L - 1;
         const Intr k = g.lv[lvl].k;
-        ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+        ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
             for (int base = 0; base < n; base += 64) {
                 const int i = base + lane;
                 float x, y, iz;
@@ -498,13 +603,11 @@ __global__ __launch_bounds__(64 * RW_WPB) void lm_ref_track_kernel(Geom g, const
             out_stats[pair].change_keyframe = (optical_flow >= 1.0f) ? 1 : 0;
         }
     }
-    REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
-    REFW_ADD(5, 1);
     if (out_stats) {  // usable candidates per level (diagnostics)
         for (int lvl = 0; lvl < g.L; ++lvl) {
-            if constexpr (DENSE) {
+            if constexpr (SRC != REF_SRC_SLIM) {
                 int mine = 0;
-                ref_with_source<true>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+                ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
                     for (int i = lane; i < n; i += 64) {
                         int x, y;
                         float iz;
@@ -530,29 +633,270 @@ __global__ __launch_bounds__(64 * RW_WPB) void lm_ref_track_kernel(Geom g, const
     }
 }
 
-// Wavefronts per workgroup: a large batch packs four pairs into a workgroup (fewer, fuller workgroups); a small one spreads its pairs
-// over the CUs one wavefront each. VORS_REF_WPB overrides (1, 2 or 4).
+// Tracker::track for a batch (inverse_compositional.rs:177-224): one WAVEFRONT per frame pair, all levels; the wavefronts of a
+// workgroup share nothing but the LDS allocation.
+template <bool HUBER, int SRC>
+__global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                                   const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                   const uint16_t* __restrict__ kf_depth, Records rec,
+                                                                   const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
+                                                                   float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
+                                                                   vors_pair_stats* __restrict__ out_stats, int n_pairs) {
+    __shared__ __attribute__((aligned(16))) float lds_all[RW_WPB * RW_WORDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (pair >= n_pairs) return;
+    float* lds = lds_all + wave * RW_WORDS;
+    REFW_T0(t_kernel);
+    const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
+    const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
+    Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177
+    bool went_well = true;
+    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
+        const RefImg c = ref_level_img<SRC>(g, cur0, curu, rec, pair, lvl);
+        int nb_iter = 0, n_full = 0;
+        float energy = 0.f, lm_coef = 0.f;
+        bool ok = false;
+        ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+            ok = refw_solve_level<HUBER>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
+        });
+        if (out_stats && lane == 0) {
+            out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
+            out_stats[pair].nb_grad_evals[lvl] = ok ? n_full : 0;
+            out_stats[pair].energy[lvl] = ok ? energy : 0.f;
+        }
+        if (!ok) {
+            went_well = false;
+            if (out_stats && lane == 0)
+                for (int l2 = lvl - 1; l2 >= 0; --l2) {
+                    out_stats[pair].nb_iter[l2] = 0;
+                    out_stats[pair].nb_grad_evals[l2] = 0;
+                    out_stats[pair].energy[l2] = 0.f;
+                }
+            break;
+        }
+    }
+    REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
+    REFW_ADD(5, 1);
+    ref_finish_pair<SRC>(g, pair, kf0, kfu, kf_depth, rec, lm_model, went_well, prev_pose, kf_pose, lds, out_poses7, out_status, out_stats);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same tracker by a WORKGROUP per frame pair (small batches, the single tracker): wavefront 0 owns the 28 chains and the LM state,
+// wavefronts 1 .. P each evaluate every P-th group of 64 points and leave its product block in LDS. Chunks of P blocks, double-buffered:
+// while wavefront 0 walks the blocks of chunk ch - 1 in list order (330 cycles of dependent additions per block: the floor of this
+// arithmetic), the producers fill chunk ch; one s_barrier per chunk. After the last block wavefront 0 takes the verdict, step() and
+// publishes what comes next (a model to evaluate, or the level's result) BEFORE the evaluation's last barrier, so an evaluation costs
+// nchunks + 1 barriers and nothing else is exchanged. The sums do not depend on P: the chains are the same chains.
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only. __syncthreads() is a release + acquire over every address space, and on gfx9 loads and
+// stores share vmcnt: it would wait for the tap and record requests the producers keep in flight ACROSS the barrier (their pipeline)
+// — every chunk would last a full memory round trip. Everything the wavefronts of a pair exchange lives in LDS.
+__device__ __forceinline__ void refc_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct RefcShared {
+    float model[7];  // REF_LM_EVAL: the model to evaluate next; REF_LM_DONE: the level's result
+    int cmd;
+    int cnt[2];      // inside points of the evaluation in progress (producers add), alternating per evaluation
+};
+
+// One evaluation at `model` by the whole workgroup. Wavefront 0 returns with the sums in `acc` after having called publish(acc, n_inside)
+// before the last barrier; the producers return after that barrier.
+template <bool HUBER, class Src, class Publish>
+__device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* slots, RefcShared& sh, int P, int parity,
+                                          Publish&& publish) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int ngroups = (n + 63) >> 6, nchunks = (ngroups + P - 1) / P;
+    const int p = wave - 1;  // producer index
+    float acc = 0.f;
+    int cnt = 0;
+    typename Src::Raw raw_cur = {}, raw_nxt = {}, raw_ahead = {};
+    RefTap tap_a = {}, tap_b = {};
+    if (wave != 0 && n > 0) {  // the producer's software pipeline over ITS groups p, p + P, ... (refw_eval)
+        raw_cur = src.load(min(p * 64 + lane, n - 1));
+        V3 Pt;
+        bool valid;
+        src.point(raw_cur, &Pt, &valid);
+        tap_a = refw_warp<Src::kTransposed>(Pt, valid && p * 64 + lane < n, c, model);
+        tap_b = tap_a;
+        raw_nxt = raw_cur;
+        raw_ahead = src.load(min((p + P) * 64 + lane, n - 1));
+    }
+    auto chunk = [&](int ch, const RefTap& tap_cur, RefTap& tap_nxt) {
+        if (wave != 0) {
+            if (ch < nchunks) {
+                const int g = ch * P + p;
+                raw_nxt = refw_moved(raw_ahead);
+                {
+                    V3 Pt;
+                    bool valid;
+                    src.point(raw_nxt, &Pt, &valid);
+                    tap_nxt = refw_warp<Src::kTransposed>(Pt, valid && (g + P) * 64 + lane < n, c, model);
+                }
+                raw_ahead = src.load(min((g + 2 * P) * 64 + lane, n - 1));
+                float J[6], tmpl, pr[RW_NSUM];
+                src.jac(raw_cur, J, &tmpl);
+                refw_products<HUBER, Src::kTransposed>(tap_cur, tmpl, J, c.huber, pr, nullptr);
+                cnt += __popcll(__ballot(tap_cur.inside));
+                float* block = slots + ((ch & 1) * P + p) * RW_WORDS;
+#pragma unroll
+                for (int k = 0; k < RW_NSUM; ++k) block[k * RW_STRIDE + lane] = pr[k];
+                raw_cur = raw_nxt;
+                if (ch == nchunks - 1 && lane == 0 && cnt != 0) atomicAdd(&sh.cnt[parity], cnt);
+            }
+        } else {
+            REFW_T0(t_c0);
+            if (ch > 0) refw_consume<8>(slots + ((ch - 1) & 1) * P * RW_WORDS, min(P, ngroups - (ch - 1) * P), RW_WORDS, acc);
+            REFW_T0(t_c1);
+            if (ch == nchunks) publish(acc, sh.cnt[parity]);  // (the producers' counts arrived before the previous barrier)
+            REFW_ADD(0, t_c1 - t_c0);
+            REFW_ADD(6, __builtin_readcyclecounter() - t_c1);
+        }
+        REFW_T0(t_b0);
+        refc_barrier();
+        if (wave == 0) REFW_ADD(7, __builtin_readcyclecounter() - t_b0);
+        if (wave == 0) REFW_ADD(2, 1);
+    };
+    for (int ch = 0; ch <= nchunks; ch += 2) {
+        chunk(ch, tap_a, tap_b);
+        if (ch + 1 <= nchunks) chunk(ch + 1, tap_b, tap_a);
+    }
+}
+
+template <bool HUBER, int SRC>
+__global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
+                                                                const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                const uint16_t* __restrict__ kf_depth, Records rec,
+                                                                const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
+                                                                float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
+                                                                vors_pair_stats* __restrict__ out_stats, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float refc_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int P = (int)(blockDim.x >> 6) - 1;
+    float* slots = refc_lds;
+    RefcShared& sh = *reinterpret_cast<RefcShared*>(refc_lds + 2 * P * RW_WORDS);
+    const int pair = blockIdx.x;
+    REFW_T0(t_kernel);
+    if (threadIdx.x == 0) {
+        sh.cnt[0] = 0;
+        sh.cnt[1] = 0;
+    }
+    __syncthreads();
+    const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
+    const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
+    Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177 (every wavefront alike)
+    bool went_well = true;
+    int parity = 0;
+    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
+        const RefImg c = ref_level_img<SRC>(g, cur0, curu, rec, pair, lvl);
+        RefLm s;
+        ref_lm_begin(s, lm_model);
+        int cmd = REF_LM_EVAL;
+        ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+            Iso eval_model = lm_model;
+            do {
+                refc_eval<HUBER>(src, n, c, eval_model, slots, sh, P, parity, [&](float acc, int cnt) {
+                    const int next = ref_lm_advance(s, acc, cnt);
+                    if (lane == 0) {
+                        iso_store(next == REF_LM_EVAL ? s.cand : s.cur_model, sh.model);
+                        sh.cmd = next;
+                        sh.cnt[parity ^ 1] = 0;
+                    }
+                });
+                parity ^= 1;
+                cmd = __builtin_amdgcn_readfirstlane(sh.cmd);
+                eval_model = ref_iso_uniform(iso_load(sh.model));
+            } while (cmd == REF_LM_EVAL);
+            lm_model = eval_model;  // REF_LM_DONE: the level's result; REF_LM_FAIL: the last kept model (not used any further)
+        });
+        const bool ok = cmd == REF_LM_DONE;
+        if (wave == 0) lm_model = ok ? s.cur_model : lm_model;
+        if (out_stats && threadIdx.x == 0) {
+            out_stats[pair].nb_iter[lvl] = ok ? s.nb_iter : 0;
+            out_stats[pair].nb_grad_evals[lvl] = ok ? s.n_full : 0;
+            out_stats[pair].energy[lvl] = ok ? s.cur_energy : 0.f;
+        }
+        if (!ok) {
+            went_well = false;
+            if (out_stats && threadIdx.x == 0)
+                for (int l2 = lvl - 1; l2 >= 0; --l2) {
+                    out_stats[pair].nb_iter[l2] = 0;
+                    out_stats[pair].nb_grad_evals[l2] = 0;
+                    out_stats[pair].energy[l2] = 0.f;
+                }
+            break;
+        }
+    }
+    if (wave != 0) return;  // (no barrier below)
+    REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
+    REFW_ADD(5, 1);
+    ref_finish_pair<SRC>(g, pair, kf0, kfu, kf_depth, rec, lm_model, went_well, prev_pose, kf_pose, slots, out_poses7, out_status, out_stats);
+}
+
+// Wavefronts per workgroup of the one-wavefront-per-pair kernel: four pairs to a workgroup (one wavefront per SIMD: single-wavefront
+// workgroups pile up on the SIMDs unevenly — measured: 2.84 ms instead of 1.68 ms per 4096 coarse-to-fine pairs). VORS_REF_WPB overrides (1, 2 or 4).
 static int refw_waves_per_block(int n_pairs) {
-    int wpb = n_pairs >= 2048 ? RW_WPB : (n_pairs >= 1024 ? 2 : 1);
+    int wpb = RW_WPB;
     if (const char* e = getenv("VORS_REF_WPB")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) wpb = v;
     }
     return wpb;
 }
+// Wavefronts per PAIR: a batch that cannot fill the chip with one wavefront per pair gets a workgroup per pair (2, 4 or 8 wavefronts: 1, 3
+// or 7 producers; LDS 2 x P x 7.6 KB). VORS_REF_COOP overrides (0 = one wavefront per pair, 2 / 4 / 8).
+static int refc_waves_per_pair(int n_pairs) {
+    int w = n_pairs <= 320 ? 8 : (n_pairs <= 1280 ? 4 : 0);
+    if (const char* e = getenv("VORS_REF_COOP")) {
+        const int v = atoi(e);
+        if (v == 0 || v == 2 || v == 4 || v == 8) w = v;
+    }
+    return w;
+}
 
 void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, const float* prev_poses7,
                                const float* kf_poses7, float* out_poses7, int32_t* out_status, vors_pair_stats* out_stats, int n_pairs,
                                hipStream_t s) {
+    const bool huber = g.huber_delta > 0.f;
+    // dense mode: the column-major planes (capi.cpp allocates and fills them for every REFERENCE handle); without them, the gathering source
+    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.kf0 ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
+    const int coop = refc_waves_per_pair(n_pairs);
+#define VORS_REF_DISPATCH(KERNEL)                                                                              \
+    do {                                                                                                       \
+        if (src == REF_SRC_DENSE_T) {                                                                          \
+            if (huber) VORS_REF_LAUNCH((KERNEL<true, REF_SRC_DENSE_T>));                                       \
+            else VORS_REF_LAUNCH((KERNEL<false, REF_SRC_DENSE_T>));                                            \
+        } else if (src == REF_SRC_DENSE_ROWMAJOR) {                                                            \
+            if (huber) VORS_REF_LAUNCH((KERNEL<true, REF_SRC_DENSE_ROWMAJOR>));                                \
+            else VORS_REF_LAUNCH((KERNEL<false, REF_SRC_DENSE_ROWMAJOR>));                                     \
+        } else {                                                                                               \
+            if (huber) VORS_REF_LAUNCH((KERNEL<true, REF_SRC_SLIM>));                                          \
+            else VORS_REF_LAUNCH((KERNEL<false, REF_SRC_SLIM>));                                               \
+        }                                                                                                      \
+    } while (0)
+    if (coop) {
+        const size_t lds = (size_t)2 * (coop - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
+        // (a launch may ask for more than 64 KB of dynamic LDS only after the kernel has been told so; per device, hence not cached in a static)
+#define VORS_REF_LAUNCH(K)                                                                                                                  \
+    do {                                                                                                                                    \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(K, dim3(n_pairs), dim3(64 * coop), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
+                           kf_poses7, out_poses7, out_status, out_stats, n_pairs);                                                         \
+    } while (0)
+        VORS_REF_DISPATCH(lm_ref_track_coop_kernel);
+#undef VORS_REF_LAUNCH
+        return;
+    }
     const int wpb = refw_waves_per_block(n_pairs);
-#define VORS_REF_ARGS dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
-                      kf_poses7, out_poses7, out_status, out_stats, n_pairs
-    const bool dense = g.mode == VORS_CANDIDATES_DENSE, huber = g.huber_delta > 0.f;
-    if (dense && huber) hipLaunchKernelGGL((lm_ref_track_kernel<true, true>), VORS_REF_ARGS);
-    else if (dense) hipLaunchKernelGGL((lm_ref_track_kernel<false, true>), VORS_REF_ARGS);
-    else if (huber) hipLaunchKernelGGL((lm_ref_track_kernel<true, false>), VORS_REF_ARGS);
-    else hipLaunchKernelGGL((lm_ref_track_kernel<false, false>), VORS_REF_ARGS);
-#undef VORS_REF_ARGS
+#define VORS_REF_LAUNCH(K)                                                                                                                            \
+    hipLaunchKernelGGL(K, dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
+                       kf_poses7, out_poses7, out_status, out_stats, n_pairs)
+    VORS_REF_DISPATCH(lm_ref_track_kernel);
+#undef VORS_REF_LAUNCH
 }
 
 #ifdef VORS_REFW_TIMING
@@ -577,15 +921,15 @@ __device__ __forceinline__ void refw_store29(float acc, int cnt, float* out29) {
 }
 
 // One evaluation of one level of one pair of a prepared batch (vors_batch_eval_level in the REFERENCE arithmetic) -> 29 sums.
-template <bool HUBER, bool DENSE>
+template <bool HUBER, int SRC>
 __global__ __launch_bounds__(64) void lm_ref_eval_level_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                                const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                const uint16_t* __restrict__ kf_depth, Records rec, int pair, int lvl,
                                                                const float* __restrict__ model7, float* __restrict__ out29) {
     __shared__ __attribute__((aligned(16))) float lds[RW_WORDS];
     const Iso model = ref_iso_uniform(iso_load(model7));
-    const RefImg c = ref_level_img(g, cur0, curu, pair, lvl);
-    ref_with_source<DENSE>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
+    const RefImg c = ref_level_img<SRC>(g, cur0, curu, rec, pair, lvl);
+    ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
         int cnt;
         const float acc = refw_eval<HUBER>(src, n, c, model, lds, &cnt);
         refw_store29(acc, cnt, out29);
@@ -593,13 +937,60 @@ __global__ __launch_bounds__(64) void lm_ref_eval_level_kernel(Geom g, const uin
 }
 void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
                                     const float* model7, float* out29, hipStream_t s) {
-#define VORS_REF_ARGS dim3(1), dim3(64), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29
-    const bool dense = g.mode == VORS_CANDIDATES_DENSE, huber = g.huber_delta > 0.f;
-    if (dense && huber) hipLaunchKernelGGL((lm_ref_eval_level_kernel<true, true>), VORS_REF_ARGS);
-    else if (dense) hipLaunchKernelGGL((lm_ref_eval_level_kernel<false, true>), VORS_REF_ARGS);
-    else if (huber) hipLaunchKernelGGL((lm_ref_eval_level_kernel<true, false>), VORS_REF_ARGS);
-    else hipLaunchKernelGGL((lm_ref_eval_level_kernel<false, false>), VORS_REF_ARGS);
-#undef VORS_REF_ARGS
+    const bool huber = g.huber_delta > 0.f;
+    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.kf0 ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
+#define VORS_REF_LAUNCH(K) hipLaunchKernelGGL(K, dim3(1), dim3(64), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29)
+    VORS_REF_DISPATCH(lm_ref_eval_level_kernel);
+#undef VORS_REF_LAUNCH
+#undef VORS_REF_DISPATCH
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dense mode: the column-major planes (engine.h RefDensePlanes). One tile kernel for bytes, 16-bit depths and f32 inverse depths:
+// a TILE x TILE block goes through LDS, read along the source rows, written along the destination rows (= source columns).
+// ------------------------------------------------------------------------------------------------------------
+template <class T, int TILE>
+__global__ __launch_bounds__(256) void ref_transpose_kernel(Geom g, const T* __restrict__ src, size_t src_stride, T* __restrict__ dst, size_t dst_stride,
+                                                            int rows, int cols) {
+    __shared__ T tile[TILE][TILE + 1];
+    const int pair = select_pair(g, blockIdx.z);
+    if (pair < 0) return;
+    const T* sp = src + (size_t)pair * src_stride;
+    T* dp = dst + (size_t)pair * dst_stride;
+    constexpr int TY = 256 / TILE;
+    const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    for (int j = ty; j < TILE; j += TY)
+        if (y0 + j < rows && x0 + tx < cols) tile[j][tx] = sp[(size_t)(y0 + j) * cols + x0 + tx];
+    __syncthreads();
+    for (int j = ty; j < TILE; j += TY)  // destination row x0 + j (a source column), TILE consecutive source rows of it
+        if (x0 + j < cols && y0 + tx < rows) dp[(size_t)(x0 + j) * rows + y0 + tx] = tile[tx][j];
+}
+template <class T>
+static void ref_transpose(const Geom& g, const T* src, size_t src_stride, T* dst, size_t dst_stride, int rows, int cols, int n_pairs, hipStream_t s) {
+    constexpr int TILE = sizeof(T) == 1 ? 64 : 32;
+    hipLaunchKernelGGL((ref_transpose_kernel<T, TILE>), dim3((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE, n_pairs), dim3(256), 0, s, g, src,
+                       src_stride, dst, dst_stride, rows, cols);
+}
+static void ref_transpose_pyramid(const Geom& g, Pyramid p, uint8_t* t0, uint8_t* tu, int n_pairs, hipStream_t s) {
+    ref_transpose<uint8_t>(g, p.level0, (size_t)g.S0, t0, (size_t)g.S0, g.lv[0].rows, g.lv[0].cols, n_pairs, s);
+    for (int l = 1; l < g.L; ++l)
+        ref_transpose<uint8_t>(g, p.upper + g.lv[l].img_off, (size_t)g.upper_stride, tu + g.lv[l].img_off, (size_t)g.upper_stride, g.lv[l].rows,
+                               g.lv[l].cols, n_pairs, s);
+}
+void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
+    const RefDensePlanes& t = rec.dense_t;
+    if (g.mode != VORS_CANDIDATES_DENSE || !t.kf0) return;
+    ref_transpose_pyramid(g, kf, t.kf0, t.kfu, n_pairs, s);
+    ref_transpose<uint16_t>(g, depth, (size_t)g.S0, t.depth, (size_t)g.S0, g.lv[0].rows, g.lv[0].cols, n_pairs, s);
+    for (int l = 1; l < g.L; ++l)
+        ref_transpose<float>(g, rec.IZ + g.lv[l].slot_off, (size_t)g.slots_total, t.iz + g.lv[l].slot_off, (size_t)g.slots_total, g.lv[l].rows,
+                             g.lv[l].cols, n_pairs, s);
+}
+void launch_ref_dense_planes_current(const Geom& g, Pyramid cur, Records rec, int n_pairs, hipStream_t s) {
+    const RefDensePlanes& t = rec.dense_t;
+    if (g.mode != VORS_CANDIDATES_DENSE || !t.cur0) return;
+    ref_transpose_pyramid(g, cur, t.cur0, t.curu, n_pairs, s);
 }
 
 // ---- operator level on explicit observations, sums in the order of the observations (the reference's eval on that Obs) --------------
