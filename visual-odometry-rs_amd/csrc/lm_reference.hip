@@ -31,6 +31,7 @@
 
 #include "device_common.h"
 #include "engine.h"
+#include "lie_g.h"
 
 namespace vors {
 
@@ -66,6 +67,21 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
     __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
         *tmpl = (float)(r.tg & 0xffu);
         warp_jacobian_at_rt((float)slim_gx(r.tg), (float)slim_gy(r.tg), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, IntrFast{k, fu, fv}, J);
+    }
+    // two points per lane (lie_g.h); FAST: both focal lengths are verified fast divisors
+    template <bool FAST>
+    __device__ __forceinline__ void point2(const Raw& ra, const Raw& rb, V3G<F2>* P, bool* va, bool* vb) const {
+        const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
+        *P = g_back_project<FAST>(IntrFast{k, fu, fv}, x, y, 1.0f / F2{ra.iz, rb.iz});
+        *va = true;
+        *vb = true;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void jac2(const Raw& ra, const Raw& rb, F2 J[6], F2* tmpl) const {
+        *tmpl = F2{(float)(ra.tg & 0xffu), (float)(rb.tg & 0xffu)};
+        const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
+        g_warp_jacobian_at<FAST>(F2{(float)slim_gx(ra.tg), (float)slim_gx(rb.tg)}, F2{(float)slim_gy(ra.tg), (float)slim_gy(rb.tg)}, x, y,
+                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, J);
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* iz, bool* valid) const {
         const SlimRec r = S[(unsigned)i];
@@ -138,6 +154,7 @@ struct RefDenseTSrc {
     int lvl, rows, cols, fine_rows;
     uint32_t magic;          // floor(2^32 / rows) + 1: i / rows == __umulhi(i, magic) for i * rows < 2^32 (i < 2^21, rows <= 2^11)
     Intr k;
+    FastDiv fu, fv;          // (point2 / jac2; the one-point forms divide)
     struct Raw {
         uint32_t xy;   // x | y << 16
         float iz;      // inverse depth (anything when !valid)
@@ -192,6 +209,20 @@ struct RefDenseTSrc {
         *tmpl = (float)(r.tgv & 0xffu);
         warp_jacobian_at((float)slim_gx(r.tgv), (float)slim_gy(r.tgv), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, k, J);
     }
+    template <bool FAST>
+    __device__ __forceinline__ void point2(const Raw& ra, const Raw& rb, V3G<F2>* P, bool* va, bool* vb) const {
+        const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
+        *P = g_back_project<FAST>(IntrFast{k, fu, fv}, x, y, 1.0f / F2{ra.iz, rb.iz});
+        *va = (ra.tgv >> 31) != 0u;
+        *vb = (rb.tgv >> 31) != 0u;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void jac2(const Raw& ra, const Raw& rb, F2 J[6], F2* tmpl) const {
+        *tmpl = F2{(float)(ra.tgv & 0xffu), (float)(rb.tgv & 0xffu)};
+        const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
+        g_warp_jacobian_at<FAST>(F2{(float)slim_gx(ra.tgv), (float)slim_gx(rb.tgv)}, F2{(float)slim_gy(ra.tgv), (float)slim_gy(rb.tgv)}, x, y,
+                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, J);
+    }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* izv, bool* valid) const {
         int xi, yi;
         raw(i, &xi, &yi, izv, valid);
@@ -243,6 +274,74 @@ __device__ __forceinline__ RefTap refw_warp(const V3& P, bool valid, const RefIm
     t.fa = u - uf;
     t.fb = v - vf;
     return t;
+}
+
+// The same for the two points of a lane (lie_g.h).
+struct RefTap2 {
+    F2 fa, fb;
+    uint32_t t0a, t1a, t0b, t1b;
+    bool ina, inb;
+};
+template <bool TR>
+__device__ __forceinline__ RefTap2 refw_warp2(const V3G<F2>& P, bool va, bool vb, const RefImg& c, const Iso& model) {
+    F2 u, v;
+    g_project_uv(c.k, g_iso_transform_point(model, P), &u, &v);
+    const F2 uf = g_floor(u), vf = g_floor(v);
+    const float cmax = (float)(c.cols - 2), rmax = (float)(c.rows - 2);
+    RefTap2 t;
+    t.ina = va && (uf.a >= 0.f) && (uf.a < cmax) && (vf.a >= 0.f) && (vf.a < rmax);
+    t.inb = vb && (uf.b >= 0.f) && (uf.b < cmax) && (vf.b >= 0.f) && (vf.b < rmax);
+    const unsigned pitch = (unsigned)(TR ? c.rows : c.cols);
+    const unsigned offa = t.ina ? (TR ? (unsigned)((int)uf.a * c.rows + (int)vf.a) : (unsigned)((int)vf.a * c.cols + (int)uf.a)) : 0u;
+    const unsigned offb = t.inb ? (TR ? (unsigned)((int)uf.b * c.rows + (int)vf.b) : (unsigned)((int)vf.b * c.cols + (int)uf.b)) : 0u;
+    uint16_t a0, a1, b0, b1;
+    __builtin_memcpy(&a0, c.img + offa, 2);
+    __builtin_memcpy(&b0, c.img + offb, 2);
+    __builtin_memcpy(&a1, c.img + (offa + pitch), 2);
+    __builtin_memcpy(&b1, c.img + (offb + pitch), 2);
+    t.t0a = a0; t.t1a = a1; t.t0b = b0; t.t1b = b1;
+    t.fa = u - uf;
+    t.fb = v - vf;
+    return t;
+}
+// interpolate + residual of both points -> (r, J) with outside points zeroed, (w, loss term) for the Huber extension
+template <bool HUBER, bool TR>
+__device__ __forceinline__ void refw_residual2(const RefTap2& t, F2 tmpl, float huber, F2 J[6], F2* e, F2* wr, F2* w) {
+    const F2 vu_00{(float)(t.t0a & 0xffu), (float)(t.t0b & 0xffu)}, vu_01{(float)(TR ? t.t1a & 0xffu : t.t0a >> 8), (float)(TR ? t.t1b & 0xffu : t.t0b >> 8)};
+    const F2 vu_10{(float)(TR ? t.t0a >> 8 : t.t1a & 0xffu), (float)(TR ? t.t0b >> 8 : t.t1b & 0xffu)}, vu_11{(float)(t.t1a >> 8), (float)(t.t1b >> 8)};
+    const F2 fa = t.fa, fb = t.fb;
+    const F2 im = (1.0f - fb) * (1.0f - fa) * vu_00 + fb * (1.0f - fa) * vu_10 + (1.0f - fb) * fa * vu_01 + fb * fa * vu_11;
+    const F2 r_in = im - tmpl;
+    const F2 r{t.ina ? r_in.a : 0.f, t.inb ? r_in.b : 0.f};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) J[q] = F2{t.ina ? J[q].a : 0.f, t.inb ? J[q].b : 0.f};
+    if (HUBER) {
+        const F2 ar{fabsf(r.a), fabsf(r.b)};
+        const bool qa = ar.a <= huber, qb = ar.b <= huber;
+        const F2 lin = huber * (2.0f * ar - huber), rr = r * r, wdiv = huber / ar;
+        *e = F2{qa ? rr.a : lin.a, qb ? rr.b : lin.b};
+        *w = F2{qa ? 1.0f : wdiv.a, qb ? 1.0f : wdiv.b};
+        *wr = *w * r;
+    } else {
+        *e = r * r;
+        *wr = r;
+        *w = F2{1.0f, 1.0f};
+    }
+}
+// the 28 products of one of the two points (refw_products)
+template <bool HUBER>
+__device__ __forceinline__ void refw_products_of(const float J[6], float e, float wr, float w, float pr[RW_NSUM]) {
+    pr[0] = e;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pr[1 + q] = J[q] * wr;
+    int k = 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int s2 = q; s2 < 6; ++s2) {
+            const float jj = J[q] * J[s2];
+            pr[k++] = HUBER ? w * jj : jj;
+        }
 }
 
 // interpolate + residual, then the 28 PRODUCTS the reference adds to its sums for this point — each rounded once, exactly the values of
@@ -417,6 +516,91 @@ __device__ __forceinline__ float refw_eval(const Src& src, int n, const RefImg& 
     return acc;
 }
 
+// refw_eval with TWO points per lane: 128 points per trip (the lane's points are 64 apart, so each half is one 64-point product block),
+// the warp, the interpolation and the Jacobian written for both points at once (lie_g.h: instruction-level parallelism 2 instead of 1 —
+// the per-point arithmetic is chains of dependent f32 operations, which on gfx950 issue every 4.6 cycles instead of every 2.6 whatever
+// the occupancy). The two product blocks go through the wavefront's one LDS buffer one after the other, each followed by its 64 additions
+// per chain — the order of the list. Same pipeline as refw_eval: the tap requests of the next 128 points and the record requests of the
+// 128 after those travel while this trip's chains run. Sources with point2 / jac2 only (candidate lists, column-major dense planes).
+template <bool HUBER, bool FAST, class Src>
+__device__ __forceinline__ float refw_eval2(const Src& src, int n, const RefImg& c, const Iso& model, float* lds, int* n_inside) {
+    constexpr bool TR = Src::kTransposed;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    int cnt = 0;
+    *n_inside = 0;
+    if (n <= 0) return acc;
+    REFW_T0(t_begin);
+    const int ntrips = (n + 127) >> 7;
+    struct Raw2 {
+        typename Src::Raw a, b;
+    };
+    auto load2 = [&](int t) { return Raw2{src.load(min(t * 128 + lane, n - 1)), src.load(min(t * 128 + 64 + lane, n - 1))}; };
+    auto warp2 = [&](const Raw2& r, int t) {
+        V3G<F2> P;
+        bool va, vb;
+        src.template point2<FAST>(r.a, r.b, &P, &va, &vb);
+        return refw_warp2<TR>(P, va && t * 128 + lane < n, vb && t * 128 + 64 + lane < n, c, model);
+    };
+    Raw2 raw_cur = load2(0), raw_nxt = raw_cur, raw_ahead = raw_cur;
+    RefTap2 tap_a = warp2(raw_cur, 0), tap_b = tap_a;
+    raw_ahead = load2(1);
+    auto trip = [&](int t, const RefTap2& tap_cur, RefTap2& tap_nxt) {
+        raw_nxt = refw_moved(raw_ahead);  // (unconditional requests, clamped indices: see refw_eval)
+        tap_nxt = warp2(raw_nxt, t + 1);
+#if defined(VORS_REFW_DOUBLE) && (VORS_REFW_DOUBLE & 4)
+        { Raw2 r2 = refw_moved(raw_nxt); RefTap2 t2 = warp2(r2, t + 1); if (t2.fa.a == 12345.678f && t2.t0a == 77u && t2.t1b == 78u && t2.t0b == 3u && t2.t1a == 5u) cnt += 1; }
+#endif
+        raw_ahead = load2(t + 2);
+        F2 J[6], tmpl, e, wr, w;
+        src.template jac2<FAST>(raw_cur.a, raw_cur.b, J, &tmpl);
+        refw_residual2<HUBER, TR>(tap_cur, tmpl, c.huber, J, &e, &wr, &w);
+        cnt += __popcll(__ballot(tap_cur.ina)) + __popcll(__ballot(tap_cur.inb));
+        {
+            float Ja[6], pr[RW_NSUM];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Ja[q] = J[q].a;
+            refw_products_of<HUBER>(Ja, e.a, wr.a, w.a, pr);
+#pragma unroll
+            for (int k = 0; k < RW_NSUM; ++k) lds[k * RW_STRIDE + lane] = pr[k];
+#if defined(VORS_REFW_DOUBLE) && (VORS_REFW_DOUBLE & 8)
+            refw_lds_fence();
+            asm volatile("" : "+v"(Ja[0]), "+v"(Ja[1]), "+v"(Ja[2]), "+v"(Ja[3]), "+v"(Ja[4]), "+v"(Ja[5]));
+            refw_products_of<HUBER>(Ja, e.a, wr.a, w.a, pr);
+#pragma unroll
+            for (int k = 0; k < RW_NSUM; ++k) lds[k * RW_STRIDE + lane] = pr[k];
+#endif
+        }
+        refw_lds_fence();
+        refw_consume<4>(lds, 1, 0, acc);
+#if defined(VORS_REFW_DOUBLE) && (VORS_REFW_DOUBLE & 1)
+        { float acc2 = acc; refw_consume<4>(lds, 1, 0, acc2); if (acc2 == 12345.678f) acc += 1.0f; }
+#endif
+        refw_lds_fence();
+        if (t * 128 + 64 < n) {  // (uniform; the second half of the last trip may be empty)
+            float Jb[6], pr[RW_NSUM];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jb[q] = J[q].b;
+            refw_products_of<HUBER>(Jb, e.b, wr.b, w.b, pr);
+#pragma unroll
+            for (int k = 0; k < RW_NSUM; ++k) lds[k * RW_STRIDE + lane] = pr[k];
+            refw_lds_fence();
+            refw_consume<4>(lds, 1, 0, acc);
+            refw_lds_fence();
+        }
+        raw_cur = raw_nxt;
+    };
+    for (int t = 0; t < ntrips; t += 2) {
+        trip(t, tap_a, tap_b);
+        if (t + 1 < ntrips) trip(t + 1, tap_b, tap_a);
+    }
+    *n_inside = cnt;
+    REFW_ADD(0, __builtin_readcyclecounter() - t_begin);
+    REFW_ADD(2, (n + 63) >> 6);
+    REFW_ADD(3, 1);
+    return acc;
+}
+
 __device__ __forceinline__ float ref_uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ Iso ref_iso_uniform(const Iso& m) {
     return Iso{V3{ref_uniform_f(m.t.x), ref_uniform_f(m.t.y), ref_uniform_f(m.t.z)},
@@ -494,12 +678,15 @@ __device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt) {
     s.nb_iter += 1;
     REFW_T0(t_step);
     const bool ok = refw_step(s.kept, s.cur_model, s.lm_coef, &s.cand);
+#if defined(VORS_REFW_DOUBLE) && (VORS_REFW_DOUBLE & 2)
+    { Iso c2; float k2 = refw_moved(s.kept); const bool ok2 = refw_step(k2, s.cur_model, s.lm_coef, &c2); if (ok2 != ok || c2.t.x != s.cand.t.x) s.n_full += 1000; }
+#endif
     REFW_ADD(1, __builtin_readcyclecounter() - t_step);
     return ok ? REF_LM_EVAL : REF_LM_FAIL;
 }
 
-// One level by one wavefront.
-template <bool HUBER, class Src>
+// One level by one wavefront. G2: two points per lane (refw_eval2; FAST: the level's focal lengths are verified fast divisors).
+template <bool HUBER, int G2, class Src>
 __device__ bool refw_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
                                  int* n_full_out, float* lds) {
     RefLm s;
@@ -507,7 +694,10 @@ __device__ bool refw_solve_level(const Src& src, int n, const RefImg& c, Iso* mo
     int cmd;
     do {
         int cnt;
-        const float acc = refw_eval<HUBER>(src, n, c, s.cand, lds, &cnt);
+        float acc;
+        if constexpr (G2 == 2) acc = refw_eval2<HUBER, true>(src, n, c, s.cand, lds, &cnt);
+        else if constexpr (G2 == 1) acc = refw_eval2<HUBER, false>(src, n, c, s.cand, lds, &cnt);
+        else acc = refw_eval<HUBER>(src, n, c, s.cand, lds, &cnt);
         cmd = ref_lm_advance(s, acc, cnt);
     } while (cmd == REF_LM_EVAL);
     if (cmd == REF_LM_FAIL) return false;
@@ -540,7 +730,7 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
         const RefDensePlanes& t = rec.dense_t;
         RefDenseTSrc src{level_ptr(g, t.kf0, t.kfu, pair, lvl), lvl > 0 ? level_ptr(g, t.kf0, t.kfu, pair, lvl - 1) : nullptr,
                          t.depth + (size_t)pair * g.S0, lvl > 0 ? t.iz + (size_t)pair * g.slots_total + lg.slot_off : nullptr, g.depth_scale,
-                         lvl, lg.rows, lg.cols, lvl > 0 ? g.lv[lvl - 1].rows : 0, 0xffffffffu / (unsigned)lg.rows + 1u, lg.k};
+                         lvl, lg.rows, lg.cols, lvl > 0 ? g.lv[lvl - 1].rows : 0, 0xffffffffu / (unsigned)lg.rows + 1u, lg.k, lg.fu, lg.fv};
         f(src, lg.rows * lg.cols);
     } else if constexpr (SRC == REF_SRC_DENSE_ROWMAJOR) {
         RefDenseSrc src{&g, kf0, kfu, kf_depth + (size_t)pair * g.S0, lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr,
@@ -635,7 +825,7 @@ __device__ __forceinline__ void ref_finish_pair(const Geom& g, int pair, const u
 
 // Tracker::track for a batch (inverse_compositional.rs:177-224): one WAVEFRONT per frame pair, all levels; the wavefronts of a
 // workgroup share nothing but the LDS allocation.
-template <bool HUBER, int SRC>
+template <bool HUBER, int SRC, bool FAST>
 __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                                    const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                    const uint16_t* __restrict__ kf_depth, Records rec,
@@ -658,7 +848,9 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
         float energy = 0.f, lm_coef = 0.f;
         bool ok = false;
         ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
-            ok = refw_solve_level<HUBER>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
+            // two points per lane wherever the source offers it; FAST: every level's focal lengths are verified fast divisors (host-checked)
+            // (the dense sources stay with one point per lane: two of them need more than the 128 registers that four wavefronts per SIMD leave)
+            ok = refw_solve_level<HUBER, SRC != REF_SRC_SLIM ? 0 : (FAST ? 2 : 1)>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
         });
         if (out_stats && lane == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
@@ -895,7 +1087,22 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
 #define VORS_REF_LAUNCH(K)                                                                                                                            \
     hipLaunchKernelGGL(K, dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
                        kf_poses7, out_poses7, out_status, out_stats, n_pairs)
-    VORS_REF_DISPATCH(lm_ref_track_kernel);
+    bool all_fast = true;
+    for (int l = 0; l < g.L; ++l) all_fast = all_fast && g.lv[l].fu.ok && g.lv[l].fv.ok;
+    if (src == REF_SRC_DENSE_ROWMAJOR) {
+        if (huber) VORS_REF_LAUNCH((lm_ref_track_kernel<true, REF_SRC_DENSE_ROWMAJOR, false>));
+        else VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_DENSE_ROWMAJOR, false>));
+    } else if (src == REF_SRC_DENSE_T) {
+        if (huber && all_fast) VORS_REF_LAUNCH((lm_ref_track_kernel<true, REF_SRC_DENSE_T, true>));
+        else if (huber) VORS_REF_LAUNCH((lm_ref_track_kernel<true, REF_SRC_DENSE_T, false>));
+        else if (all_fast) VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_DENSE_T, true>));
+        else VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_DENSE_T, false>));
+    } else {
+        if (huber && all_fast) VORS_REF_LAUNCH((lm_ref_track_kernel<true, REF_SRC_SLIM, true>));
+        else if (huber) VORS_REF_LAUNCH((lm_ref_track_kernel<true, REF_SRC_SLIM, false>));
+        else if (all_fast) VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_SLIM, true>));
+        else VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_SLIM, false>));
+    }
 #undef VORS_REF_LAUNCH
 }
 
@@ -1026,7 +1233,7 @@ __global__ __launch_bounds__(64) void lm_ref_solve_obs_kernel(RefObsSrc src, int
     Iso model = ref_iso_uniform(iso_load(model7));
     int nb_iter = 0, n_full = 0;
     float energy = 0.f, lm_coef = 0.f;
-    const bool ok = refw_solve_level<HUBER>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, lds);
+    const bool ok = refw_solve_level<HUBER, 0>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, lds);
     if (threadIdx.x == 0) {
         iso_store(model, out);
         out[7] = (float)nb_iter;
