@@ -43,26 +43,27 @@ enum { VORS_ROW_MAJOR = 0, VORS_COL_MAJOR = 1 };
  *     counter-based hash instead of the reference's unseeded thread_rng. */
 enum { VORS_CANDIDATES_COARSE_TO_FINE = 0, VORS_CANDIDATES_DENSE = 1, VORS_CANDIDATES_DSO = 2 };
 
-/* Per-point arithmetic of the LM evaluation (f32 in both modes; integer stages, the inside test, the order of the sums and the LM
- * control flow do not depend on it).
- * 0 = EXACT: every per-point expression in the reference's evaluation order without FMA contraction — inverse depths, Jacobians
- *     and per-point residuals are bit-identical to the reference's arithmetic (the parity anchor).
- * 1 = FUSED: algebraically equivalent shorter forms (warp through the homography K R K^-1 plus _z K t with one hardware
- *     reciprocal, lerp-form bilinear interpolation, factored Jacobian; FMA) on the levels of MANY points; a level of at most 2500 points
- *     (VORS_FUSED_EXACT_POINTS) and every near-identity model is evaluated in the EXACT arithmetic, because the energy of a few hundred
- *     points carries the fused warp's per-point rounding above the reference's own summation noise and forks the LM path.
- *     Per-point values agree to a few ulp. Parity statement (measured, 640x480 6 levels, bench.py `parity`): the fraction of pairs
- *     beyond 1e-4 rad / 1e-4 m of the oracle equals that of EXACT and of the oracle against its own f64-accumulation build (~0.05 %:
- *     pairs whose LM path forks on the ORDER of the f32 sums); it is NOT zero for any arithmetic, and pyramids of < 5 levels on large
- *     images exceed 1e-4 from summation order alone (DESIGN.md §4 "short pyramids"). About 1.5-2x as fast as EXACT.
- * 2 = REFERENCE: EXACT's per-point arithmetic AND the reference's summation: candidates in extract_z's column-major order
- *     (inverse_compositional.rs:260-279; the lists are sorted once per keyframe), `energy_sum += r * r`, `gradient += jac * r`,
- *     `hessian += hes` (lm_optimizer.rs:72-84,94-100) as sequential f32 multiply-then-add chains, one lane per sum, the optical-flow
- *     sum of the keyframe test likewise, and sinf / cosf of se3::exp as glibc computes them. The device then takes the oracle's LM path
- *     decision for decision: iteration counts equal at every level and poses BIT-IDENTICAL to the oracle's (tests/test_gpu_reference.py,
- *     bench.py `parity_reference`) — the deterministic parity anchor that EXACT and FUSED are gated against. 2-3x slower than EXACT
- *     (the chain of dependent additions); every candidate mode, Huber, the trackers and the operator level support it. */
-enum { VORS_ARITH_EXACT = 0, VORS_ARITH_FUSED = 1, VORS_ARITH_REFERENCE = 2 };
+/* Arithmetic of the LM evaluation (f32 in every mode; the integer stages, the inside test and the LM control flow do not depend on it).
+ * The reference has no such choice (Config, inverse_compositional.rs:37-49): ZERO — what a zero-initialised vors_config, the Rust shim of
+ * INTEGRATION.md, the vors_track CLI, host/tracker.hpp and vors_amd.Config select — is the mode that reproduces it.
+ * 0 = REFERENCE: every per-point expression in the reference's evaluation order without FMA contraction AND the reference's summation:
+ *     candidates in extract_z's column-major order (inverse_compositional.rs:260-279), `energy_sum += r * r`, `gradient += jac * r`,
+ *     `hessian += hes` (lm_optimizer.rs:72-84,94-100) as sequential f32 multiply-then-add chains in that order, the optical-flow sum of
+ *     the keyframe test likewise, sinf / cosf of se3::exp as glibc computes them. The device takes the oracle's LM path decision for
+ *     decision: iteration counts equal at every level, poses BIT-IDENTICAL to the oracle's (tests/test_gpu_reference.py, bench.py
+ *     `parity_reference`: 4096 / 4096 pairs per candidate mode, 64 / 64 sequences). Every candidate mode, Huber, the trackers and the
+ *     operator level support it. Cost (640x480, 6 levels, 4096 pairs, MI355X): see `reference` in bench.py's line.
+ * 1 = EXACT: the same per-point arithmetic (inverse depths, Jacobians, residuals bit-identical to the reference's), sums in the
+ *     device's tree order. The LM loop's accept / stop comparisons (lm_optimizer.rs:144,179) are decided at ties, so a different order
+ *     of the additions forks the loop in some pairs: measured tail beyond 1e-4 rad / 1e-4 m of the oracle — per 4096 pairs:
+ *     coarse-to-fine 3, DSO 14, dense 0; per 64 sequences x 39 frames: 1-2 coarse-to-fine, 6-8 DSO (the oracle against its own
+ *     f64-accumulation build shows the same counts: it is the order, not the precision).
+ * 2 = FUSED: algebraically equivalent shorter forms (warp through the homography K R K^-1 plus _z K t with one hardware reciprocal,
+ *     lerp-form bilinear interpolation, factored Jacobian; FMA) on the levels of MANY points; a level of at most 2500 points
+ *     (VORS_FUSED_EXACT_POINTS) and every near-identity model is evaluated in the EXACT arithmetic. Per-point values agree
+ *     to a few ulp; the tail beyond 1e-4 equals EXACT's (per 4096 pairs: coarse-to-fine 3, DSO 10, dense 0). The fastest mode: what
+ *     bench.py's headline times. Pyramids of < 5 levels on large images exceed 1e-4 from summation order alone in modes 1 and 2. */
+enum { VORS_ARITH_REFERENCE = 0, VORS_ARITH_EXACT = 1, VORS_ARITH_FUSED = 2 };
 
 /* Per-pair tracking status. Mirrors `optimization_went_well` (inverse_compositional.rs:180,195-199,206-208). */
 enum { VORS_TRACK_OK = 0, VORS_TRACK_OPTIMIZER_FAILED_POSE_KEPT = 1 };
@@ -106,7 +107,8 @@ vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uin
 int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level
                               * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version, vors_pipeline_*, vors_device_info,
                               *    vors_tracker_track_checked
-                              * 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos */
+                              * 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos
+                              * 5: VORS_ARITH_* renumbered: 0 = REFERENCE (a zero-initialised vors_config reproduces the reference), 1 = EXACT, 2 = FUSED */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces

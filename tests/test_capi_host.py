@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(V.EXPORTED_SYMBOLS)
-    assert lib.vors_abi_version() == 4   # 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos
+    assert lib.vors_abi_version() == 5   # 5: VORS_ARITH_* renumbered, 0 = REFERENCE
 
 
 def test_struct_layouts_match_header():

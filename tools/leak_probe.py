@@ -7,7 +7,7 @@ import numpy as np, torch
 import vors_amd as V
 rows, cols, L = 240, 320, 5
 intr = V.scaled_intrinsics(rows, cols)
-cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=1)
+cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=V.ARITH_FUSED)
 kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED0000, 64, rows, cols, intr)
 outs = [(torch.zeros((64, 7), device="cuda"), torch.zeros(64, dtype=torch.int32, device="cuda")) for _ in range(6)]
 torch.cuda.synchronize()

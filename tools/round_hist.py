@@ -6,7 +6,7 @@ import numpy as np, torch
 import vors_amd as V
 rows, cols, L, n = 480, 640, 6, 4096
 intr = V.scaled_intrinsics(rows, cols)
-cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=1)
+cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=V.ARITH_FUSED)
 b = V.Batch(cfg, n, rows, cols)
 kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED0000, n, rows, cols, intr)
 poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda"); stats = V.stats_tensor(n)

@@ -29,7 +29,7 @@ for i in range(n_cases):
         ok = (status.cpu().numpy() == ref["status"]).all() and (st["n_points"][:, :L] == ref["n_points"]).all()
         good = ref["status"] == 0
         err = np.abs(poses.cpu().numpy() - ref["poses"])[good].max(initial=0)
-        if arith == 2:
+        if arith == V.ARITH_REFERENCE:
             same = (poses.cpu().numpy().view(np.uint32) == ref["poses"].view(np.uint32))[good].all() and (st["nb_iter"][:, :L] == ref["nb_iter"])[good].all()
             n_ref_identical += int(bool(ok and same))
             if not (ok and same):

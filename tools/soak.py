@@ -30,7 +30,7 @@ for mode in (0, 1, 2):
 g = np.random.default_rng(0).integers(0, 255, (rows, cols), dtype=np.uint8)
 d = np.full((rows, cols), 9000, np.uint16)
 for mode in (0, 1, 2):
-    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=1)
+    cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=V.ARITH_FUSED)
     for it in range(40):
         t = cfg.init(0.0, d, 0.0, g)
         for k in range(3):
@@ -48,7 +48,7 @@ for mode in (0, 1, 2):
     print(f"mode {mode}: 40 trackers + 20 lock-step handles created / tracked / destroyed; free memory delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")
 
 # throughput-mode pipelines: create / feed / destroy with steps still in flight at destruction
-cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=1)
+cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=1, arithmetic=V.ARITH_FUSED)
 kg, kd, cg, _, _ = V.synth_render_pairs(0x5EED0000, 64, rows, cols, intr)
 for it in range(20):
     pipe = V.Pipeline(cfg, 64, rows, cols, depth=2 + it % 2)

@@ -8,7 +8,7 @@ rows, cols, L = 480, 640, 6
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 mode = {"dense": 1, "c2f": 0}[sys.argv[2] if len(sys.argv) > 2 else "dense"]
 intr = V.scaled_intrinsics(rows, cols)
-cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=1)
+cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=V.ARITH_FUSED)
 for nstreams in (1, 2, 3):
     ws = []
     for k in range(nstreams):

@@ -246,7 +246,7 @@ int vors_device_count(void) {
     }
     return n;
 }
-int vors_abi_version(void) { return 4; }
+int vors_abi_version(void) { return 5; }
 
 vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes) {
     vors_status st = require_device();

@@ -80,7 +80,7 @@ struct Config {  // inverse_compositional.rs:37-49
     // extensions (zero = reference behaviour)
     int candidates_mode = VORS_CANDIDATES_COARSE_TO_FINE;
     Float huber_delta = 0.0f;
-    int arithmetic = VORS_ARITH_EXACT;  // VORS_ARITH_FUSED: ~2x faster per-point arithmetic, poses within the 1e-4 parity bar
+    int arithmetic = VORS_ARITH_REFERENCE;  // the reference's arithmetic and summation order (bit-identical poses); VORS_ARITH_FUSED: the fastest, poses within 1e-4 but for a measured tail (include/vors_hip.h)
 
     vors_config to_c() const {
         return vors_config{(int32_t)nb_levels, (int32_t)candidates_diff_threshold, depth_scale, intrinsics.principal_point.first,

@@ -3,7 +3,7 @@
 // Reads a TUM RGB-D associations file, initialises the tracker with the first RGB-D frame, tracks every following frame
 // and prints one trajectory line `timestamp tx ty tz qx qy qz qw` per tracked frame on stdout (vors_track.rs:46-64).
 // Optional trailing flags (not in the reference): `--quiet` silences the per-frame stderr logs; `--arith exact|fused|reference` selects the
-// per-point arithmetic (include/vors_hip.h VORS_ARITH_*, default exact); `--candidates c2f|dense|dso` the level-0 mask source
+// per-point arithmetic (include/vors_hip.h VORS_ARITH_*, default reference); `--candidates c2f|dense|dso` the level-0 mask source
 // (default c2f = the reference's coarse-to-fine selection).
 #include <cstdio>
 #include <cstring>
@@ -36,14 +36,14 @@ static std::string join(const std::string& parent, const std::string& rel) {  //
 
 int main(int argc, char** argv) {
     bool quiet = false;
-    int arithmetic = VORS_ARITH_EXACT, candidates = VORS_CANDIDATES_COARSE_TO_FINE;
+    int arithmetic = VORS_ARITH_REFERENCE, candidates = VORS_CANDIDATES_COARSE_TO_FINE;
     bool bad_flag = false;
     for (int a = 3; a < argc && !bad_flag; ++a) {  // extension flags follow the reference's two positional arguments
         const std::string flag = argv[a], val = a + 1 < argc ? argv[a + 1] : "";
         if (flag == "--quiet") {
             quiet = true;
         } else if (flag == "--arith" && (val == "exact" || val == "fused" || val == "reference")) {
-            arithmetic = val == "fused" ? VORS_ARITH_FUSED : (val == "reference" ? VORS_ARITH_REFERENCE : VORS_ARITH_EXACT);
+            arithmetic = val == "fused" ? VORS_ARITH_FUSED : (val == "exact" ? VORS_ARITH_EXACT : VORS_ARITH_REFERENCE);
             ++a;
         } else if (flag == "--candidates" && (val == "c2f" || val == "dense" || val == "dso")) {
             candidates = val == "dense" ? VORS_CANDIDATES_DENSE : (val == "dso" ? VORS_CANDIDATES_DSO : VORS_CANDIDATES_COARSE_TO_FINE);

@@ -26,7 +26,7 @@ MAX_LEVELS = 8
 ROW_MAJOR, COL_MAJOR = 0, 1
 CANDIDATES_COARSE_TO_FINE, CANDIDATES_DENSE, CANDIDATES_DSO = 0, 1, 2
 TRACK_OK, TRACK_OPTIMIZER_FAILED_POSE_KEPT = 0, 1
-ARITH_EXACT, ARITH_FUSED, ARITH_REFERENCE = 0, 1, 2
+ARITH_REFERENCE, ARITH_EXACT, ARITH_FUSED = 0, 1, 2  # 0 = the reference's own arithmetic AND summation order (bit-identical poses)
 
 
 class VorsError(RuntimeError):
@@ -248,7 +248,7 @@ class Config:
     """src/core/track/inverse_compositional.rs:37-49 (+ two extension fields, zero = reference behaviour)."""
 
     def __init__(self, nb_levels=6, candidates_diff_threshold=7, depth_scale=DEPTH_SCALE, intrinsics=INTRINSICS_FR1,
-                 idepth_variance=0.0001, candidates_mode=CANDIDATES_COARSE_TO_FINE, huber_delta=0.0, arithmetic=ARITH_EXACT):
+                 idepth_variance=0.0001, candidates_mode=CANDIDATES_COARSE_TO_FINE, huber_delta=0.0, arithmetic=ARITH_REFERENCE):
         self.nb_levels = nb_levels
         self.candidates_diff_threshold = candidates_diff_threshold
         self.depth_scale = depth_scale
@@ -684,7 +684,7 @@ def synth_render_pairs(seed0, n_pairs, rows, cols, cam5, motion_scale=1.0, inval
 class Obs:
     """lm_optimizer.rs:43-58 (hessians are recomputed on the device, not passed)."""
 
-    def __init__(self, intrinsics5, template, image, coordinates, _z_candidates, jacobians, huber_delta=0.0, arithmetic=ARITH_EXACT):
+    def __init__(self, intrinsics5, template, image, coordinates, _z_candidates, jacobians, huber_delta=0.0, arithmetic=ARITH_REFERENCE):
         self.intrinsics = np.ascontiguousarray(intrinsics5, np.float32)
         self.template = np.ascontiguousarray(template, np.uint8)
         self.image = np.ascontiguousarray(image, np.uint8)
