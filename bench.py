@@ -520,6 +520,49 @@ def reference_parity(V, args, device, seed0, sizes):
     return out
 
 
+def reference_block(V, args, device, seed0, ring):
+    """The three candidate modes in VORS_ARITH_REFERENCE — the boundary's default arithmetic (vors_config.arithmetic = 0), the one whose
+    poses are bit-identical to the oracle's (`parity_reference`) — at the headline batch size: throughput, stage times, the LM stage's
+    algorithmic-byte rate against the HBM peak, and the 512-pair step (BASELINE config 4's per-GPU share) with its step-time ratio."""
+    import copy
+    a = copy.copy(args)
+    a.arith = "reference"
+    out = {"arithmetic": "reference (VORS_ARITH_REFERENCE = 0: the reference's per-point arithmetic and summation order)"}
+    for mode in ("c2f", "dso", "dense"):
+        steps = args.steps if mode != "dense" else max(2, min(args.steps, 5))   # (a dense step is ~70 ms at 4096 pairs)
+        w = Workload(V, a, mode, device, seed0)
+        w.batch.enable_kernel_timing(ring)
+        dt = timed_run(w, steps, min(args.warmup, 2), 1, None, None)
+        st = V.decode_stats(w.stats)
+        io, lmb, _, ev, _ = byte_model(st, a.levels, a.rows, a.cols, mode == "dense")
+        lm = float(w.batch.kernel_times("lm")[-steps:].mean())
+        kf = float(w.batch.kernel_times("keyframe")[-steps:].mean())
+        py = float((w.batch.kernel_times("pyramid_keyframe")[-steps:] + w.batch.kernel_times("pyramid_current")[-steps:]).mean())
+        lm_bytes = lmb + 32 * a.pairs
+        blk = {"value": round(a.pairs * steps / dt, 2), "unit": "frame-pairs/s", "pairs_per_gpu": a.pairs, "ms_per_step": round(dt / steps * 1e3, 4),
+               "stages_ms": {"pyramids": round(py, 5), "keyframe": round(kf, 5), "lm": round(lm, 5)},
+               "lm_evals_per_pair": round(ev, 2),
+               "roofline": {"bound": "hbm", "limited_by": "valu (dependent f32 chains + the reference's per-point expressions)", "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "kernel": "lm_ref_track_kernel",
+                            "achieved": round(lm_bytes / (lm * 1e-3) / 1e9, 2), "frac": round(lm_bytes / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                            "algorithmic_bytes_per_launch": lm_bytes, "kernel_ms_avg": round(lm, 5),
+                            "io_only_GBps": round(io * steps / dt / 1e9, 2), "io_only_frac": round(io * steps / dt / 1e9 / HBM_PEAK_GBPS, 5),
+                            "whole_job_frac": round((io + lmb) * steps / dt / 1e9 / HBM_PEAK_GBPS, 5)}}
+        del w
+        if a.pairs != 512:
+            a5 = copy.copy(a)
+            a5.pairs = 512
+            w5 = Workload(V, a5, mode, device, seed0)
+            w5.batch.enable_kernel_timing(ring)
+            dt5 = timed_run(w5, steps, min(args.warmup, 2), 1, None, None)
+            blk["batch_512"] = {"value": round(512 * steps / dt5, 2), "ms_per_step": round(dt5 / steps * 1e3, 4),
+                                "lm_kernel_ms": round(float(w5.batch.kernel_times("lm")[-steps:].mean()), 5),
+                                "step_time_ratio_vs_headline_batch": round((dt / steps) / (dt5 / steps), 3)}
+            del w5
+        out[mode] = blk
+    return out
+
+
 def parity_sample_sizes(args):
     """Pairs compared per candidates mode: 1024 dense / 4096 sparse at 640x480 on a many-core host (the oracle takes ~15 s / ~3 s on 256
     threads), scaled down with the host's core count and up-sized images so that the default run stays within minutes."""
@@ -772,11 +815,12 @@ def main():
                                             "ms_per_step": round(dt3 / args.steps * 1e3, 4),
                                             "note": "vors_pipeline_* with depth 2: steps alternate between two batch handles on two internal streams; not the headline"}
             del pipe, w3
+        if not args.no_secondary and args.arith != "reference":
+            out["reference"] = reference_block(V, args, device, seed0, ring)
         if not args.no_sequences and not args.no_secondary:
             out["sequences_64"] = sequences_bench(V, args, device)
         if not args.no_secondary and args.parity_pairs != 0 and args.arith != "reference":
             sizes = parity_sample_sizes(args)
-            sizes["dense"] = min(sizes["dense"], 512)   # (the dense REFERENCE mode walks 409,500 points per evaluation sequentially)
             out["parity_reference"] = reference_parity(V, args, device, seed0, sizes)
         if args.cpu_pairs != 0:
             out["cpu_baseline"] = cpu_baseline(args, main_w, value)
