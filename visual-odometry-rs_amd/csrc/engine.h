@@ -211,6 +211,7 @@ void launch_lm_track_fused(const Geom& g, Pyramid cur, Pyramid kf, const uint16_
 // REFERENCE arithmetic (lm_reference.hip): the candidate lists of n_pairs pairs into extract_z's column-major order (no-op in dense mode;
 // honours Geom::sel_list), and the tracker with the reference's sequential sums.
 void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s);
+bool ref_rank_from_regions(const Geom& g, const Records& rec);  // coarse-to-fine: launch_sort_colmajor ranks the staged regions itself (no compaction first)
 // dense mode: the column-major planes of the keyframe side (pyramid, depth map, inverse depths of levels >= 1; honours Geom::sel_list) and
 // of the current frame's pyramid -> rec.dense_t
 void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);

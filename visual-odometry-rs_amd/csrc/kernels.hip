@@ -856,7 +856,9 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else if (r == 2) hipLaunchKernelGGL(keyframe_sparse_kernel<2>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         else hipLaunchKernelGGL(keyframe_sparse_kernel<1>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
-        hipLaunchKernelGGL(compact_regions_kernel, dim3(n_pairs <= 1024 ? g.L : 1, n_pairs), dim3(256), 0, s, g, rec);
+        // (REFERENCE arithmetic: launch_sort_colmajor, which every caller runs next, packs AND orders the regions in one pass — lm_reference.hip)
+        if (!ref_rank_from_regions(g, rec))
+            hipLaunchKernelGGL(compact_regions_kernel, dim3(n_pairs <= 1024 ? g.L : 1, n_pairs), dim3(256), 0, s, g, rec);
     }
 }
 

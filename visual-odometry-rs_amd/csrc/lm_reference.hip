@@ -1420,8 +1420,123 @@ __global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6)))
         }
     }
 }
+// ------------------------------------------------------------------------------------------------------------
+// Coarse-to-fine mode: the same ranking straight from the keyframe kernel's staged regions (kernels.hip keyframe_sparse_kernel leaves the
+// points of each wavefront region at the front of the region's slots + a count per region) — compaction AND sort in one pass: every
+// thread keeps the coordinates of RANK_U slots in registers (a slot holds a point iff its position in the region is below the region's
+// count), the whole key space of the level is ONE LDS bitmap (640x480: 9600 words + 16-bit word prefixes, 57.6 KB; larger levels take
+// several segments), a point's rank = set bits below its key, and the record goes from the staging grid to its final place in the list.
+// Replaces compact_regions_kernel + sort_colmajor_kernel (0.23 + 0.40 ms per 4096 pairs) whenever every level fits RANK_U slots per thread.
+// ------------------------------------------------------------------------------------------------------------
+#define RANK_WORDS 9600  // at most 307,200 keys per segment (57.6 KB of LDS)
+#define RANK_BLOCK 512
+#define RANK_U_MAX 40    // slots per thread: levels of at most 20,480 slots (640x480 6 levels: 9,600; 1280x960 7 levels: 19,200)
+#define RANK_MAX_REGIONS 1024
+// One launch per level: RANK_U slots per thread and `seg_words` words of bitmap (dynamic LDS) sized for THAT level, so that the small levels
+// run many workgroups per CU instead of inheriting level 0's 58 KB and 40 predicated loads per thread.
+template <int RANK_U>
+__global__ __launch_bounds__(RANK_BLOCK) void rank_regions_kernel(Geom g, Records rec, int l, int seg_words) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_lds[];
+    uint32_t* bits = rank_lds;                                             // [seg_words]
+    uint16_t* wpre = reinterpret_cast<uint16_t*>(rank_lds + seg_words);    // [seg_words] set bits in the words before this one (a level has < 65536 points)
+    __shared__ int s_cnt[RANK_MAX_REGIONS];
+    __shared__ int wsum[RANK_BLOCK / 64];
+    __shared__ int s_base;
+    const int pair = select_pair(g, blockIdx.x);
+    if (pair < 0) return;
+    const int rows = g.lv[l].rows, cols = g.lv[l].cols;
+    const unsigned nkeys = (unsigned)rows * (unsigned)cols;
+    const int n_slots = g.lv[l].n_slots;
+    const int cap_sh = (__ffs(rec.kf_r) - 1) + (g.L - 1 - l);  // log2 of the slots per region at this level
+    const size_t lvl0 = (size_t)pair * g.slots_total + g.lv[l].slot_off;
+    const SlimRec* src = rec.stage + lvl0;
+    SlimRec* dst = rec.S + lvl0;
+    const int* cnt = rec.region_cnt + ((size_t)pair * VORS_MAX_LEVELS + l) * rec.n_regions;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = threadIdx.x; r < rec.n_regions; r += RANK_BLOCK) s_cnt[r] = cnt[r];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    SlimRec r[RANK_U];  // (whole records: one read of the staging grid, no dependent second one once the rank is known)
+#pragma unroll
+    for (int u = 0; u < RANK_U; ++u) {
+        const int j = (int)threadIdx.x + u * RANK_BLOCK;
+        const bool valid = j < n_slots && (j & ((1 << cap_sh) - 1)) < s_cnt[j >> cap_sh];
+        r[u] = valid ? src[j] : SlimRec{0xffffffffu, 0.f, 0u};
+    }
+    for (unsigned seg0 = 0; seg0 < nkeys; seg0 += (unsigned)seg_words * 32u) {
+        const unsigned seg_keys = min(nkeys - seg0, (unsigned)seg_words * 32u);
+        const int words = (int)((seg_keys + 31u) >> 5);
+        const int wpt = (words + RANK_BLOCK - 1) / RANK_BLOCK;  // consecutive words per thread
+        for (int w = threadIdx.x; w < words; w += RANK_BLOCK) bits[w] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RANK_U; ++u) {
+            const unsigned rel = (r[u].xy & 0xffffu) * (unsigned)rows + (r[u].xy >> 16) - seg0;
+            if (r[u].xy != 0xffffffffu && rel < seg_keys) atomicOr(&bits[rel >> 5], 1u << (rel & 31u));
+        }
+        __syncthreads();
+        const int w0 = threadIdx.x * wpt, w1 = min(words, w0 + wpt);
+        int tot = 0;
+        for (int w = w0; w < w1; ++w) tot += __popc(bits[w]);
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - tot;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        const int base = s_base;
+        for (int w = w0; w < w1; ++w) {
+            wpre[w] = (uint16_t)run;
+            run += __popc(bits[w]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RANK_U; ++u) {
+            const unsigned rel = (r[u].xy & 0xffffu) * (unsigned)rows + (r[u].xy >> 16) - seg0;
+            if (r[u].xy != 0xffffffffu && rel < seg_keys) {
+                const unsigned w = rel >> 5;
+                dst[base + (int)wpre[w] + __popc(bits[w] & ((1u << (rel & 31u)) - 1u))] = r[u];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == RANK_BLOCK - 1) s_base = base + run;  // (the last thread's running count = the segment's total)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l] = s_base;
+}
+// Whether launch_sort_colmajor takes the lists straight from the staged regions (then launch_keyframe skips compact_regions_kernel).
+// VORS_REF_RANK=0 keeps the two-kernel form (A/B, tests).
+bool ref_rank_from_regions(const Geom& g, const Records& rec) {
+    if (g.arith != VORS_ARITH_REFERENCE || g.mode != VORS_CANDIDATES_COARSE_TO_FINE || !rec.stage || rec.n_regions > RANK_MAX_REGIONS) return false;
+    if (const char* e = getenv("VORS_REF_RANK"))
+        if (atoi(e) == 0) return false;
+    for (int l = 0; l < g.L; ++l)
+        if (g.lv[l].n_slots > RANK_U_MAX * RANK_BLOCK || g.lv[l].n_slots >= 65536) return false;
+    return true;
+}
+
 void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s) {
     if (g.mode == VORS_CANDIDATES_DENSE || !rec.sort_tmp) return;
+    if (ref_rank_from_regions(g, rec)) {
+        for (int l = 0; l < g.L; ++l) {
+            const int u = (g.lv[l].n_slots + RANK_BLOCK - 1) / RANK_BLOCK;
+            const int words = std::min(RANK_WORDS, (g.lv[l].rows * g.lv[l].cols + 31) / 32);
+            const size_t lds = (size_t)words * 6;
+#define VORS_RANK_LAUNCH(U) hipLaunchKernelGGL(rank_regions_kernel<U>, dim3(n_pairs), dim3(RANK_BLOCK), lds, s, g, rec, l, words)
+            if (u <= 1) VORS_RANK_LAUNCH(1);
+            else if (u <= 2) VORS_RANK_LAUNCH(2);
+            else if (u <= 5) VORS_RANK_LAUNCH(5);
+            else if (u <= 10) VORS_RANK_LAUNCH(10);
+            else if (u <= 20) VORS_RANK_LAUNCH(20);
+            else VORS_RANK_LAUNCH(RANK_U_MAX);
+#undef VORS_RANK_LAUNCH
+        }
+        return;
+    }
     // VORS_REF_SORT_REGCAP (read per launch; tests): lists longer than this take the multi-pass form through the scratch copy — 0 forces it
     // for every list; the default is what 8 records per thread hold
     const char* e = getenv("VORS_REF_SORT_REGCAP");
