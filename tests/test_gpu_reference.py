@@ -278,3 +278,29 @@ def test_single_tracker_equals_the_oracle_tracker_bit_for_bit(mode):
         assert same_bits(ot.keyframe_pose()[1], vt.keyframe()[1])
         switches += int(ol["changed_keyframe"])
     assert switches >= 1
+
+
+# ---------------------------------------------------------------------------------------------- the kernels behind the mode
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["coarse_to_fine", "dense", "dso"])
+def test_every_kernel_form_gives_the_oracles_bits(monkeypatch, mode):
+    """Round 5: the REFERENCE arithmetic runs as one wavefront per pair (large batches), as a workgroup per pair (small batches: 2, 4 or 8
+    wavefronts, one of them owning the chains) and as the first followed by the second for the pairs still iterating when most of the batch
+    is done (hand-over: LM state saved between two evaluations, restored by a workgroup). The chains are the same chains in every form:
+    iteration counts, models, poses and optical flow must equal the oracle's bit for bit in each, Huber included."""
+    rows, cols, L, n = 120, 160, 4, 24
+    intr = O.scaled_intrinsics(rows, cols)
+    for huber in (0.0, 10.0):
+        kg, kd, cg, cd, gt = synth(n, rows, cols, intr, 0x5EED9100 + mode, blocky=(mode == 2))
+        ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode, huber_delta=huber), kg, kd, cg)
+        forms = {"one wavefront per pair": {"VORS_REF_COOP": "0"},
+                 "workgroup of 2": {"VORS_REF_COOP": "2"}, "workgroup of 4": {"VORS_REF_COOP": "4"}, "workgroup of 8": {"VORS_REF_COOP": "8"},
+                 "hand-over after 25 % to workgroups of 4": {"VORS_REF_COOP": "0", "VORS_REF_HANDOFF_MIN_PAIRS": "1", "VORS_REF_HANDOFF": "25"},
+                 "hand-over after 1 pair to workgroups of 2": {"VORS_REF_COOP": "0", "VORS_REF_HANDOFF_MIN_PAIRS": "1", "VORS_REF_HANDOFF": "5",
+                                                               "VORS_REF_HANDOFF_WAVES": "2"}}
+        for name, env in forms.items():
+            for k in ("VORS_REF_COOP", "VORS_REF_HANDOFF_MIN_PAIRS", "VORS_REF_HANDOFF", "VORS_REF_HANDOFF_WAVES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b, poses, status, stats, _ = run_batch(vcfg(L, intr, mode, huber=huber), kg, kd, cg)
+            assert_pairs_identical(ref, poses, status, stats, L, f"{MODES[mode]}, huber {huber}, {name}")

@@ -181,6 +181,9 @@ static void batch_free(vors_batch* b) {
     if (b->split.ev_join) (void)hipEventDestroy(b->split.ev_join);
     if (b->split.side_list) (void)hipFree(b->split.side_list);
     if (b->split.join_list) (void)hipFree(b->split.join_list);
+    void* handoff[] = {b->rec.handoff.state, b->rec.handoff.list, b->rec.handoff.counters};
+    for (void* p : handoff)
+        if (p) (void)hipFree(p);
     void* planes[] = {b->rec.dense_t.kf0, b->rec.dense_t.kfu, b->rec.dense_t.cur0, b->rec.dense_t.curu, b->rec.dense_t.depth, b->rec.dense_t.iz};
     for (void* p : planes)
         if (p) (void)hipFree(p);
@@ -342,6 +345,11 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
             if (e == hipSuccess) e = dmalloc(&b->rec.sort_tmp, slots, &b->bytes);
             b->owns_sort_tmp = true;
         }
+    }
+    if (e == hipSuccess && g.arith == VORS_ARITH_REFERENCE) {  // straggler hand-over of large batches (engine.h RefHandoff)
+        if (e == hipSuccess) e = dmalloc(&b->rec.handoff.state, np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.handoff.list, np, &b->bytes);
+        if (e == hipSuccess) e = dmalloc(&b->rec.handoff.counters, 2, &b->bytes);
     }
     if (e == hipSuccess && g.mode == VORS_CANDIDATES_DSO) {
         const int rr = (rows + 31) / 32, rc = (cols + 31) / 32;

@@ -80,6 +80,22 @@ struct RefDensePlanes {
     float* iz;         // inverse depths of levels >= 1 (NaN = Unknown)
 };
 
+// REFERENCE arithmetic, large batches: hand-over of the pairs still iterating when most of the batch has finished (lm_reference.hip).
+// One wavefront per pair fills the chip while every pair is alive; the pairs with the most iterations then run alone, one wavefront on a
+// SIMD each, at a third of the chip's rate. Once `after` pairs are done, a wavefront that is about to start another evaluation saves its LM
+// state instead and queues its pair; a second launch gives each queued pair a whole workgroup (the same chains, bit for bit).
+struct RefResume {  // the state of optimizer::State::iterative_solve between two evaluations (lm_reference.hip RefLm) + the level
+    float cur_model[7], cand[7];
+    float kept[28];
+    float cur_energy, lm_coef;
+    int nb_iter, n_full, lvl;
+};
+struct RefHandoff {
+    RefResume* state;  // [pairs]
+    int* list;         // [pairs] queued pairs
+    int* counters;     // [0] pairs queued, [1] pairs finished by the first launch
+};
+
 struct Records {
     float4* A;
     float4* B;
@@ -96,6 +112,7 @@ struct Records {
     int n_regions;      //   regions per level (= wavefronts of the keyframe kernel per pair)
     int kf_r;           //   roots per wavefront region
     RefDensePlanes dense_t;  // REFERENCE arithmetic, dense mode (all null otherwise)
+    RefHandoff handoff;      // REFERENCE arithmetic (null otherwise)
     SlimRec* sort_tmp;  // REFERENCE arithmetic, sparse modes: scratch of the column-major sort (lm_reference.hip), laid out like S; the
                         // coarse-to-fine mode lends its staging grid, which is free once the regions have been compacted
 };

@@ -686,27 +686,65 @@ __device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt) {
 }
 
 // One level by one wavefront. G2: two points per lane (refw_eval2; FAST: the level's focal lengths are verified fast divisors).
+// The LM state between two evaluations <-> memory (engine.h RefResume): the hand-over of a straggler pair to a workgroup.
+__device__ __forceinline__ void ref_lm_save(const RefLm& s, int lvl, RefResume* r) {
+    const int lane = threadIdx.x & 63;
+    if (lane < RW_NSUM) r->kept[lane] = s.kept;
+    if (lane == 0) {
+        iso_store(s.cur_model, r->cur_model);
+        iso_store(s.cand, r->cand);
+        r->cur_energy = s.cur_energy;
+        r->lm_coef = s.lm_coef;
+        r->nb_iter = s.nb_iter;
+        r->n_full = s.n_full;
+        r->lvl = lvl;
+    }
+}
+__device__ __forceinline__ void ref_lm_restore(RefLm& s, const RefResume* r) {
+    const int lane = threadIdx.x & 63;
+    s.cur_model = ref_iso_uniform(iso_load(r->cur_model));
+    s.cand = ref_iso_uniform(iso_load(r->cand));
+    s.kept = r->kept[min(lane, RW_NSUM - 1)];
+    s.cur_energy = ref_uniform_f(r->cur_energy);
+    s.lm_coef = ref_uniform_f(r->lm_coef);
+    s.nb_iter = __builtin_amdgcn_readfirstlane(r->nb_iter);
+    s.n_full = __builtin_amdgcn_readfirstlane(r->n_full);
+    s.started = true;
+}
+
+// One level by one wavefront. G2: two points per lane (refw_eval2; FAST: the level's focal lengths are verified fast divisors).
+// Returns 1 (done), 0 (step() failed) or 2: handed over (ho_after > 0: once that many pairs of the batch have finished, the pair is queued
+// for the workgroup kernel at its next evaluation — `done` is read with a returning atomic requested BEFORE the evaluation and looked at
+// after it, so the round trip costs nothing).
 template <bool HUBER, int G2, class Src>
-__device__ bool refw_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
-                                 int* n_full_out, float* lds) {
+__device__ int refw_solve_level(const Src& src, int n, const RefImg& c, Iso* model, int* nb_iter_out, float* energy_out, float* lm_coef_out,
+                                int* n_full_out, float* lds, const RefHandoff& ho, int ho_after, int pair, int lvl) {
+    const int lane = threadIdx.x & 63;
     RefLm s;
     ref_lm_begin(s, *model);
     int cmd;
     do {
+        int finished = 0;
+        if (ho_after > 0 && lane == 0) finished = atomicAdd(&ho.counters[1], 0);
         int cnt;
         float acc;
         if constexpr (G2 == 2) acc = refw_eval2<HUBER, true>(src, n, c, s.cand, lds, &cnt);
         else if constexpr (G2 == 1) acc = refw_eval2<HUBER, false>(src, n, c, s.cand, lds, &cnt);
         else acc = refw_eval<HUBER>(src, n, c, s.cand, lds, &cnt);
         cmd = ref_lm_advance(s, acc, cnt);
+        if (ho_after > 0 && cmd == REF_LM_EVAL && __builtin_amdgcn_readfirstlane(finished) >= ho_after) {
+            ref_lm_save(s, lvl, ho.state + pair);
+            if (lane == 0) ho.list[atomicAdd(&ho.counters[0], 1)] = pair;
+            return 2;
+        }
     } while (cmd == REF_LM_EVAL);
-    if (cmd == REF_LM_FAIL) return false;
+    if (cmd == REF_LM_FAIL) return 0;
     *model = s.cur_model;
     *nb_iter_out = s.nb_iter;
     *energy_out = s.cur_energy;
     *lm_coef_out = s.lm_coef;
     *n_full_out = s.n_full;
-    return true;
+    return 1;
 }
 
 // Where the points of a level come from (template argument SRC of the kernels below).
@@ -831,7 +869,7 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
                                                                    const uint16_t* __restrict__ kf_depth, Records rec,
                                                                    const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
                                                                    float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
-                                                                   vors_pair_stats* __restrict__ out_stats, int n_pairs) {
+                                                                   vors_pair_stats* __restrict__ out_stats, int n_pairs, int ho_after) {
     __shared__ __attribute__((aligned(16))) float lds_all[RW_WPB * RW_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int pair = blockIdx.x * (int)(blockDim.x >> 6) + wave;
@@ -846,12 +884,15 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
         const RefImg c = ref_level_img<SRC>(g, cur0, curu, rec, pair, lvl);
         int nb_iter = 0, n_full = 0;
         float energy = 0.f, lm_coef = 0.f;
-        bool ok = false;
+        int how = 0;
         ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
             // two points per lane wherever the source offers it; FAST: every level's focal lengths are verified fast divisors (host-checked)
             // (the dense sources stay with one point per lane: two of them need more than the 128 registers that four wavefronts per SIMD leave)
-            ok = refw_solve_level<HUBER, SRC != REF_SRC_SLIM ? 0 : (FAST ? 2 : 1)>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds);
+            how = refw_solve_level<HUBER, SRC != REF_SRC_SLIM ? 0 : (FAST ? 2 : 1)>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds,
+                                                                                    rec.handoff, ho_after, pair, lvl);
         });
+        if (how == 2) return;  // handed over: the workgroup kernel finishes this pair (levels done so far have their statistics already)
+        const bool ok = how == 1;
         if (out_stats && lane == 0) {
             out_stats[pair].nb_iter[lvl] = ok ? nb_iter : 0;
             out_stats[pair].nb_grad_evals[lvl] = ok ? n_full : 0;
@@ -870,6 +911,7 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
     }
     REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
     REFW_ADD(5, 1);
+    if (ho_after > 0 && lane == 0) atomicAdd(&rec.handoff.counters[1], 1);  // one pair fewer to wait for (before the epilogue: the stragglers may go now)
     ref_finish_pair<SRC>(g, pair, kf0, kfu, kf_depth, rec, lm_model, went_well, prev_pose, kf_pose, lds, out_poses7, out_status, out_stats);
 }
 
@@ -965,13 +1007,17 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
                                                                 const uint16_t* __restrict__ kf_depth, Records rec,
                                                                 const float* __restrict__ prev_poses7, const float* __restrict__ kf_poses7,
                                                                 float* __restrict__ out_poses7, int32_t* __restrict__ out_status,
-                                                                vors_pair_stats* __restrict__ out_stats, int n_pairs) {
+                                                                vors_pair_stats* __restrict__ out_stats, int n_pairs, int resume) {
     extern __shared__ __attribute__((aligned(16))) float refc_lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int P = (int)(blockDim.x >> 6) - 1;
     float* slots = refc_lds;
     RefcShared& sh = *reinterpret_cast<RefcShared*>(refc_lds + 2 * P * RW_WORDS);
-    const int pair = blockIdx.x;
+    // resume: the workgroups serve the pairs the one-wavefront launch queued (engine.h RefHandoff); the others have nothing to do
+    if (resume && (int)blockIdx.x >= rec.handoff.counters[0]) return;
+    const int pair = resume ? __builtin_amdgcn_readfirstlane(rec.handoff.list[blockIdx.x]) : (int)blockIdx.x;
+    const RefResume* saved = resume ? rec.handoff.state + pair : nullptr;
+    const int first_lvl = resume ? __builtin_amdgcn_readfirstlane(saved->lvl) : g.L - 1;
     REFW_T0(t_kernel);
     if (threadIdx.x == 0) {
         sh.cnt[0] = 0;
@@ -983,10 +1029,14 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
     Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177 (every wavefront alike)
     bool went_well = true;
     int parity = 0;
-    for (int lvl = g.L - 1; lvl >= 0; --lvl) {
+    for (int lvl = first_lvl; lvl >= 0; --lvl) {
         const RefImg c = ref_level_img<SRC>(g, cur0, curu, rec, pair, lvl);
         RefLm s;
         ref_lm_begin(s, lm_model);
+        if (resume && lvl == first_lvl) {  // pick the level up where the one-wavefront launch left it: `cand` is the next model to evaluate
+            ref_lm_restore(s, saved);
+            lm_model = s.cand;
+        }
         int cmd = REF_LM_EVAL;
         ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
             Iso eval_model = lm_model;
@@ -1077,16 +1127,27 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
     do {                                                                                                                                    \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(K, dim3(n_pairs), dim3(64 * coop), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
-                           kf_poses7, out_poses7, out_status, out_stats, n_pairs);                                                         \
+                           kf_poses7, out_poses7, out_status, out_stats, n_pairs, 0);                                                      \
     } while (0)
         VORS_REF_DISPATCH(lm_ref_track_coop_kernel);
 #undef VORS_REF_LAUNCH
         return;
     }
     const int wpb = refw_waves_per_block(n_pairs);
+    // straggler hand-over (engine.h RefHandoff): once this share of the batch has finished, the pairs still iterating move to workgroups of
+    // their own. VORS_REF_HANDOFF = percent (0 = off); batches that fill the chip only.
+    int ho_after = 0;
+    int ho_min_pairs = 2048;  // VORS_REF_HANDOFF_MIN_PAIRS: tests hand small batches over
+    if (const char* e = getenv("VORS_REF_HANDOFF_MIN_PAIRS")) ho_min_pairs = std::max(1, atoi(e));
+    if (rec.handoff.state && n_pairs >= ho_min_pairs) {
+        int percent = 65;
+        if (const char* e = getenv("VORS_REF_HANDOFF")) percent = std::max(0, std::min(99, atoi(e)));
+        ho_after = (int)((long long)n_pairs * percent / 100);
+    }
+    if (ho_after > 0) (void)hipMemsetAsync(rec.handoff.counters, 0, 2 * sizeof(int), s);
 #define VORS_REF_LAUNCH(K)                                                                                                                            \
     hipLaunchKernelGGL(K, dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
-                       kf_poses7, out_poses7, out_status, out_stats, n_pairs)
+                       kf_poses7, out_poses7, out_status, out_stats, n_pairs, ho_after)
     bool all_fast = true;
     for (int l = 0; l < g.L; ++l) all_fast = all_fast && g.lv[l].fu.ok && g.lv[l].fv.ok;
     if (src == REF_SRC_DENSE_ROWMAJOR) {
@@ -1104,6 +1165,22 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         else VORS_REF_LAUNCH((lm_ref_track_kernel<false, REF_SRC_SLIM, false>));
     }
 #undef VORS_REF_LAUNCH
+    if (ho_after > 0) {  // the queued pairs, a workgroup each (at most n_pairs - ho_after of them; a workgroup beyond the queue returns at once)
+        int hw = 4;
+        if (const char* e = getenv("VORS_REF_HANDOFF_WAVES")) {
+            const int v = atoi(e);
+            if (v == 2 || v == 4 || v == 8) hw = v;
+        }
+        const size_t lds = (size_t)2 * (hw - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
+#define VORS_REF_LAUNCH(K)                                                                                                                  \
+    do {                                                                                                                                    \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(K, dim3(n_pairs - ho_after), dim3(64 * hw), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
+                           kf_poses7, out_poses7, out_status, out_stats, n_pairs, 1);                                                      \
+    } while (0)
+        VORS_REF_DISPATCH(lm_ref_track_coop_kernel);
+#undef VORS_REF_LAUNCH
+    }
 }
 
 #ifdef VORS_REFW_TIMING
@@ -1233,7 +1310,7 @@ __global__ __launch_bounds__(64) void lm_ref_solve_obs_kernel(RefObsSrc src, int
     Iso model = ref_iso_uniform(iso_load(model7));
     int nb_iter = 0, n_full = 0;
     float energy = 0.f, lm_coef = 0.f;
-    const bool ok = refw_solve_level<HUBER, 0>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, lds);
+    const bool ok = refw_solve_level<HUBER, 0>(src, n, c, &model, &nb_iter, &energy, &lm_coef, &n_full, lds, RefHandoff{nullptr, nullptr, nullptr}, 0, 0, 0) == 1;
     if (threadIdx.x == 0) {
         iso_store(model, out);
         out[7] = (float)nb_iter;
