@@ -184,7 +184,7 @@ static void batch_free(vors_batch* b) {
     void* handoff[] = {b->rec.handoff.state, b->rec.handoff.list, b->rec.handoff.counters};
     for (void* p : handoff)
         if (p) (void)hipFree(p);
-    void* planes[] = {b->rec.dense_t.kf0, b->rec.dense_t.kfu, b->rec.dense_t.cur0, b->rec.dense_t.curu, b->rec.dense_t.depth, b->rec.dense_t.iz};
+    void* planes[] = {b->rec.dense_t.recs, b->rec.dense_t.n_valid, b->rec.dense_t.cur0, b->rec.dense_t.curu};
     for (void* p : planes)
         if (p) (void)hipFree(p);
     void* extra[] = {b->dso.gmag, b->dso.median, b->dso.thresh, b->dso.max_g, b->dso.max_pos, b->dso.mask1, b->dso.picked, b->dso.state, b->dso.pick_list,
@@ -326,12 +326,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
         if (g.arith == VORS_ARITH_REFERENCE) {  // column-major copies of what the LM kernel reads (engine.h RefDensePlanes)
             RefDensePlanes& t = b->rec.dense_t;
-            if (e == hipSuccess) e = dmalloc(&t.kf0, np * g.S0, &b->bytes);
-            if (e == hipSuccess) e = dmalloc(&t.kfu, np * g.upper_stride, &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.recs, np * ((size_t)g.S0 + g.upper_stride), &b->bytes);
+            if (e == hipSuccess) e = dmalloc(&t.n_valid, np * VORS_MAX_LEVELS, &b->bytes);
             if (e == hipSuccess) e = dmalloc(&t.cur0, np * g.S0, &b->bytes);
             if (e == hipSuccess) e = dmalloc(&t.curu, np * g.upper_stride, &b->bytes);
-            if (e == hipSuccess) e = dmalloc(&t.depth, np * g.S0, &b->bytes);
-            if (e == hipSuccess) e = dmalloc(&t.iz, slots, &b->bytes);
         }
     } else {  // sparse modes: compact 12-byte candidate lists (+ the keyframe kernel's staging grid in coarse-to-fine mode)
         if (e == hipSuccess) e = dmalloc(&b->rec.S, slots, &b->bytes);

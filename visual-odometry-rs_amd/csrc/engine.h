@@ -66,18 +66,20 @@ __host__ __device__ inline int slim_gy(uint32_t tg) { return ((int)(tg << 4)) >>
 //   B = (J0, J1, J2, J3) C = (J4, J5)   warp Jacobian (inverse_compositional.rs:313-341)
 //   XY = x | y << 16     pixel coordinates (keyframe test, inspection)
 //   IZ = inverse depth   (inspection only)
-// REFERENCE arithmetic, dense mode: COLUMN-MAJOR copies of everything the LM kernel reads. The reference enumerates the pixels of a level
+// REFERENCE arithmetic, dense mode: everything the LM kernel reads, in COLUMN-MAJOR order. The reference enumerates the pixels of a level
 // column by column (DMatrix order, inverse_compositional.rs:260-279), so consecutive points of its order are consecutive ROWS: on the
-// row-major planes a wavefront's 64 points touch 64 cache lines per load, on these they touch one or two — and point i of the enumeration
-// is element i of the plane. Laid out like the originals (level 0: pair stride S0; upper levels: pair stride upper_stride, level offset
-// img_off; inverse depths of levels >= 1: pair stride slots_total, level offset slot_off), every level transposed within its own slot.
+// row-major planes a wavefront's 64 points touch 64 cache lines per load, here they touch one or two — and point i of the enumeration is
+// element i of the level.
+//   recs      per pixel of every level, 8 bytes: (inverse depth f32 — scale / depth at level 0 (inverse_depth.rs:24-29), the fused value
+//             above, NaN = Unknown — and template | gx | gy packed like SlimRec.tg): the level's Obs entry minus what the LM kernel
+//             recomputes (lm_optimizer.rs:43-58), written once per keyframe by lm_reference.hip ref_dense_records_kernel.
+//             Pair stride S0 + upper_stride entries; level 0 at 0, level l >= 1 at S0 + img_off.
+//   cur0/curu the current frame's pyramid, column-major level by level (laid out like the row-major pyramid).
 struct RefDensePlanes {
-    uint8_t* kf0;      // keyframe level 0
-    uint8_t* kfu;      // keyframe levels >= 1
-    uint8_t* cur0;     // current frame level 0
-    uint8_t* curu;     // current frame levels >= 1
-    uint16_t* depth;   // keyframe depth map (level 0)
-    float* iz;         // inverse depths of levels >= 1 (NaN = Unknown)
+    uint2* recs;
+    int* n_valid;  // [pair][VORS_MAX_LEVELS] pixels with a known inverse depth per level, counted while the records are written (diagnostics)
+    uint8_t* cur0;
+    uint8_t* curu;
 };
 
 // REFERENCE arithmetic, large batches: hand-over of the pairs still iterating when most of the batch has finished (lm_reference.hip).

@@ -143,63 +143,30 @@ struct RefDenseSrc {  // dense mode on the ROW-MAJOR planes (vors_batch_eval_lev
         *y = (float)yi;
     }
 };
-// Dense mode on the COLUMN-MAJOR planes (engine.h RefDensePlanes): pixel i of the enumeration is element i of every plane of the level.
+// Dense mode on the COLUMN-MAJOR records (engine.h RefDensePlanes): pixel i of the enumeration is record i of the level.
 struct RefDenseTSrc {
     static constexpr bool kTransposed = true;  // the current image is column-major as well
-    const uint8_t* kf;       // this level of the keyframe pyramid, column-major (level 0: gradient + template)
-    const uint8_t* kf_fine;  // the next finer level (levels >= 1: block gradient + template, gradient.rs:74-93)
-    const uint16_t* depth;   // level 0
-    const float* iz;         // levels >= 1, NaN = Unknown
-    float depth_scale;
-    int lvl, rows, cols, fine_rows;
-    uint32_t magic;          // floor(2^32 / rows) + 1: i / rows == __umulhi(i, magic) for i * rows < 2^32 (i < 2^21, rows <= 2^11)
+    const uint2* recs;   // this level of this pair: (inverse depth bits, template | gx | gy | valid << 31)
+    int rows;
+    uint32_t magic;      // floor(2^32 / rows) + 1: i / rows == __umulhi(i, magic) for i * rows < 2^32 (i < 2^21, rows <= 2^11)
     Intr k;
-    FastDiv fu, fv;          // (point2 / jac2; the one-point forms divide)
+    FastDiv fu, fv;      // (point2 / jac2; the one-point forms divide)
     struct Raw {
         uint32_t xy;   // x | y << 16
         float iz;      // inverse depth (anything when !valid)
         uint32_t tgv;  // slim_pack_tg(template, gx, gy) | valid << 31
     };
-    __device__ __forceinline__ void coords(int i, int* x, int* y) const {
-        const int xx = (int)__umulhi((unsigned)i, magic);
-        *x = xx;
-        *y = i - xx * rows;
+    __device__ __forceinline__ Raw load(int i) const {
+        const uint2 r = recs[(unsigned)i];
+        const unsigned x = __umulhi((unsigned)i, magic), y = (unsigned)i - x * (unsigned)rows;
+        return Raw{x | (y << 16), __uint_as_float(r.x), r.y};
     }
     __device__ __forceinline__ void raw(int i, int* x, int* y, float* izv, bool* valid) const {
-        coords(i, x, y);
-        if (lvl == 0) {
-            const int dz = depth[(unsigned)i];
-            *valid = dz != 0;
-            *izv = depth_scale / (float)dz;  // inverse_depth.rs:24-29
-        } else {
-            const float z = iz[(unsigned)i];
-            *valid = !(z != z);
-            *izv = z;
-        }
-    }
-    __device__ __forceinline__ Raw load(int i) const {
-        int x, y, gx, gy, tm;
-        float izv;
-        bool valid;
-        raw(i, &x, &y, &izv, &valid);
-        if (lvl == 0) {  // centred difference, truncating / 2, 1-px border = 0 (gradient.rs:15-33); neighbours in x are `rows` bytes apart
-            const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
-            const unsigned o = (unsigned)i, dx = interior ? (unsigned)rows : 0u, dy = interior ? 1u : 0u;
-            const int l0 = kf[o - dx], r0 = kf[o + dx], u0 = kf[o - dy], d0 = kf[o + dy];
-            tm = kf[o];
-            gx = (r0 - l0) / 2;
-            gy = (d0 - u0) / 2;
-        } else {  // 2x2 block of the finer level: a = (2y, 2x), b = (2y + 1, 2x), c = (2y, 2x + 1), d = (2y + 1, 2x + 1): a | b and c | d are adjacent
-            const unsigned o = __umul24((unsigned)(2 * x), (unsigned)fine_rows) + (unsigned)(2 * y);
-            uint16_t r0, r1;
-            __builtin_memcpy(&r0, kf_fine + o, 2);
-            __builtin_memcpy(&r1, kf_fine + (o + (unsigned)fine_rows), 2);
-            const int a = r0 & 0xff, b = r0 >> 8, c2 = r1 & 0xff, d = r1 >> 8;
-            gx = (c2 + d - a - b) / 2;
-            gy = (b - a + d - c2) / 2;
-            tm = (a + b + c2 + d) >> 2;  // = the level's own pixel (multires.rs:21-31)
-        }
-        return Raw{(uint32_t)x | ((uint32_t)y << 16), izv, slim_pack_tg(tm, gx, gy) | (valid ? 0x80000000u : 0u)};
+        const Raw r = load(i);
+        *x = (int)(r.xy & 0xffffu);
+        *y = (int)(r.xy >> 16);
+        *izv = r.iz;
+        *valid = (r.tgv >> 31) != 0u;
     }
     __device__ __forceinline__ void point(const Raw& r, V3* P, bool* valid) const {
         *P = back_project(k, (float)(r.xy & 0xffffu), (float)(r.xy >> 16), 1.0f / r.iz);
@@ -766,9 +733,8 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
     const LevelGeom lg = g.lv[lvl];
     if constexpr (SRC == REF_SRC_DENSE_T) {
         const RefDensePlanes& t = rec.dense_t;
-        RefDenseTSrc src{level_ptr(g, t.kf0, t.kfu, pair, lvl), lvl > 0 ? level_ptr(g, t.kf0, t.kfu, pair, lvl - 1) : nullptr,
-                         t.depth + (size_t)pair * g.S0, lvl > 0 ? t.iz + (size_t)pair * g.slots_total + lg.slot_off : nullptr, g.depth_scale,
-                         lvl, lg.rows, lg.cols, lvl > 0 ? g.lv[lvl - 1].rows : 0, 0xffffffffu / (unsigned)lg.rows + 1u, lg.k, lg.fu, lg.fv};
+        RefDenseTSrc src{t.recs + (size_t)pair * ((size_t)g.S0 + g.upper_stride) + (lvl == 0 ? 0 : g.S0 + lg.img_off), lg.rows,
+                         0xffffffffu / (unsigned)lg.rows + 1u, lg.k, lg.fu, lg.fv};
         f(src, lg.rows * lg.cols);
     } else if constexpr (SRC == REF_SRC_DENSE_ROWMAJOR) {
         RefDenseSrc src{&g, kf0, kfu, kf_depth + (size_t)pair * g.S0, lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr,
@@ -833,7 +799,9 @@ __device__ __forceinline__ void ref_finish_pair(const Geom& g, int pair, const u
     }
     if (out_stats) {  // usable candidates per level (diagnostics)
         for (int lvl = 0; lvl < g.L; ++lvl) {
-            if constexpr (SRC != REF_SRC_SLIM) {
+            if constexpr (SRC == REF_SRC_DENSE_T) {
+                if (lane == 0) out_stats[pair].n_points[lvl] = rec.dense_t.n_valid[(size_t)pair * VORS_MAX_LEVELS + lvl];
+            } else if constexpr (SRC == REF_SRC_DENSE_ROWMAJOR) {
                 int mine = 0;
                 ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
                     for (int i = lane; i < n; i += 64) {
@@ -887,8 +855,7 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
         int how = 0;
         ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
             // two points per lane wherever the source offers it; FAST: every level's focal lengths are verified fast divisors (host-checked)
-            // (the dense sources stay with one point per lane: two of them need more than the 128 registers that four wavefronts per SIMD leave)
-            how = refw_solve_level<HUBER, SRC != REF_SRC_SLIM ? 0 : (FAST ? 2 : 1)>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds,
+            how = refw_solve_level<HUBER, SRC == REF_SRC_DENSE_ROWMAJOR ? 0 : (FAST ? 2 : 1)>(src, n, c, &lm_model, &nb_iter, &energy, &lm_coef, &n_full, lds,
                                                                                     rec.handoff, ho_after, pair, lvl);
         });
         if (how == 2) return;  // handed over: the workgroup kernel finishes this pair (levels done so far have their statistics already)
@@ -1105,7 +1072,7 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
                                hipStream_t s) {
     const bool huber = g.huber_delta > 0.f;
     // dense mode: the column-major planes (capi.cpp allocates and fills them for every REFERENCE handle); without them, the gathering source
-    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.kf0 ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
+    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.recs ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
     const int coop = refc_waves_per_pair(n_pairs);
 #define VORS_REF_DISPATCH(KERNEL)                                                                              \
     do {                                                                                                       \
@@ -1222,7 +1189,7 @@ __global__ __launch_bounds__(64) void lm_ref_eval_level_kernel(Geom g, const uin
 void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, const uint16_t* kf_depth, Records rec, int pair, int lvl,
                                     const float* model7, float* out29, hipStream_t s) {
     const bool huber = g.huber_delta > 0.f;
-    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.kf0 ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
+    const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.recs ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
 #define VORS_REF_LAUNCH(K) hipLaunchKernelGGL(K, dim3(1), dim3(64), 0, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, pair, lvl, model7, out29)
     VORS_REF_DISPATCH(lm_ref_eval_level_kernel);
 #undef VORS_REF_LAUNCH
@@ -1256,25 +1223,103 @@ static void ref_transpose(const Geom& g, const T* src, size_t src_stride, T* dst
     hipLaunchKernelGGL((ref_transpose_kernel<T, TILE>), dim3((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE, n_pairs), dim3(256), 0, s, g, src,
                        src_stride, dst, dst_stride, rows, cols);
 }
-static void ref_transpose_pyramid(const Geom& g, Pyramid p, uint8_t* t0, uint8_t* tu, int n_pairs, hipStream_t s) {
-    ref_transpose<uint8_t>(g, p.level0, (size_t)g.S0, t0, (size_t)g.S0, g.lv[0].rows, g.lv[0].cols, n_pairs, s);
-    for (int l = 1; l < g.L; ++l)
-        ref_transpose<uint8_t>(g, p.upper + g.lv[l].img_off, (size_t)g.upper_stride, tu + g.lv[l].img_off, (size_t)g.upper_stride, g.lv[l].rows,
-                               g.lv[l].cols, n_pairs, s);
+// The keyframe side in one kernel per level: gradient + template of the pixel (device_common.h grad_tmpl_at: gradient.rs:15-33,74-93) and its
+// inverse depth (level 0: scale / depth, inverse_depth.rs:24-29; above: the fused plane) as ONE 8-byte record, read along the rows of the
+// row-major sources, written along the columns (32 x 64 tile through LDS).
+__global__ __launch_bounds__(256) void ref_dense_records_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
+                                                                const uint16_t* __restrict__ depth, Records rec, int l) {
+    __shared__ uint2 tile[32][65];  // 32 rows x 64 columns: a wavefront reads one row of 64 pixels, then writes 32 rows of two columns
+    const int pair = select_pair(g, blockIdx.z);
+    if (pair < 0) return;
+    const int rows = g.lv[l].rows, cols = g.lv[l].cols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 32;
+    const uint16_t* dp = depth + (size_t)pair * g.S0;
+    const float* izp = l > 0 ? rec.IZ + (size_t)pair * g.slots_total + g.lv[l].slot_off : nullptr;
+    int n_valid = 0;
+#pragma unroll 2
+    for (int j = wave; j < 32; j += 4) {
+        const int x = x0 + lane, y = y0 + j;
+        if (x < cols && y < rows) {
+            int gx, gy, tm;
+            grad_tmpl_at(g, kf0, kfu, pair, l, x, y, &gx, &gy, &tm);
+            float iz;
+            bool valid;
+            if (l == 0) {
+                const int dz = dp[(unsigned)(y * cols + x)];
+                valid = dz != 0;
+                iz = g.depth_scale / (float)dz;
+            } else {
+                iz = izp[(unsigned)(y * cols + x)];
+                valid = !(iz != iz);
+            }
+            tile[j][lane] = make_uint2(__float_as_uint(iz), slim_pack_tg(tm, gx, gy) | (valid ? 0x80000000u : 0u));
+            n_valid += valid ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n_valid += __shfl_xor(n_valid, o);
+    if (lane == 0 && n_valid != 0) atomicAdd(&rec.dense_t.n_valid[(size_t)pair * VORS_MAX_LEVELS + l], n_valid);
+    __syncthreads();
+    uint2* out = rec.dense_t.recs + (size_t)pair * ((size_t)g.S0 + g.upper_stride) + (l == 0 ? 0 : g.S0 + g.lv[l].img_off);
+    const int r = lane & 31, c2 = lane >> 5;
+#pragma unroll 2
+    for (int j = 2 * wave + c2; j < 64; j += 8)  // column x0 + j, 32 consecutive rows of it (256 bytes per half-wavefront)
+        if (x0 + j < cols && y0 + r < rows) out[(size_t)(x0 + j) * rows + y0 + r] = tile[r][j];
 }
 void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
-    const RefDensePlanes& t = rec.dense_t;
-    if (g.mode != VORS_CANDIDATES_DENSE || !t.kf0) return;
-    ref_transpose_pyramid(g, kf, t.kf0, t.kfu, n_pairs, s);
-    ref_transpose<uint16_t>(g, depth, (size_t)g.S0, t.depth, (size_t)g.S0, g.lv[0].rows, g.lv[0].cols, n_pairs, s);
-    for (int l = 1; l < g.L; ++l)
-        ref_transpose<float>(g, rec.IZ + g.lv[l].slot_off, (size_t)g.slots_total, t.iz + g.lv[l].slot_off, (size_t)g.slots_total, g.lv[l].rows,
-                             g.lv[l].cols, n_pairs, s);
+    if (g.mode != VORS_CANDIDATES_DENSE || !rec.dense_t.recs) return;
+    launch_zero_ints(g, rec.dense_t.n_valid, VORS_MAX_LEVELS, n_pairs, s);
+    for (int l = 0; l < g.L; ++l)
+        hipLaunchKernelGGL(ref_dense_records_kernel, dim3((g.lv[l].cols + 63) / 64, (g.lv[l].rows + 31) / 32, n_pairs), dim3(256), 0, s, g, kf.level0,
+                           kf.upper, depth, rec, l);
 }
+// u8 planes whose sides are multiples of 4 (level 0 of any usual image): 128 x 128 tiles, 128-byte runs and dword accesses on both sides.
+__global__ __launch_bounds__(256) void ref_transpose_u8_wide_kernel(Geom g, const uint8_t* __restrict__ src, size_t src_stride, uint8_t* __restrict__ dst,
+                                                                    size_t dst_stride, int rows, int cols) {
+    __shared__ __attribute__((aligned(16))) uint8_t t[128][132];  // t[x][y]; pitch 132: rows stay dword-aligned
+    const int pair = select_pair(g, blockIdx.z);
+    if (pair < 0) return;
+    const uint8_t* sp = src + (size_t)pair * src_stride;
+    uint8_t* dp = dst + (size_t)pair * dst_stride;
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 128;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int d = (int)threadIdx.x + 256 * k, row = d >> 5, xd = d & 31;
+        const int x = x0 + 4 * xd, y = y0 + row;
+        if (y < rows && x < cols) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(sp + (size_t)y * cols + x);
+            t[4 * xd + 0][row] = (uint8_t)v;
+            t[4 * xd + 1][row] = (uint8_t)(v >> 8);
+            t[4 * xd + 2][row] = (uint8_t)(v >> 16);
+            t[4 * xd + 3][row] = (uint8_t)(v >> 24);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int d = (int)threadIdx.x + 256 * k, col = d >> 5, yd = d & 31;
+        const int x = x0 + col, y = y0 + 4 * yd;
+        if (x < cols && y < rows) *reinterpret_cast<uint32_t*>(dp + (size_t)x * rows + y) = *reinterpret_cast<const uint32_t*>(&t[col][4 * yd]);
+    }
+}
+// The current frame's pyramid, column-major: level 0 is transposed, the levels above are the mean pyramid OF THE TRANSPOSED IMAGE — halving
+// commutes with transposition (the 2x2 mean is symmetric, both sides halve with the same floor: multires.rs:21-31,67-88), so the pyramid
+// kernel on the geometry with rows and columns exchanged writes exactly the transposed levels, in the same slots, at its streaming rate.
 void launch_ref_dense_planes_current(const Geom& g, Pyramid cur, Records rec, int n_pairs, hipStream_t s) {
     const RefDensePlanes& t = rec.dense_t;
     if (g.mode != VORS_CANDIDATES_DENSE || !t.cur0) return;
-    ref_transpose_pyramid(g, cur, t.cur0, t.curu, n_pairs, s);
+    const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+    if (rows % 4 == 0 && cols % 4 == 0 && ((uintptr_t)cur.level0) % 4 == 0 && ((uintptr_t)t.cur0) % 4 == 0)
+        hipLaunchKernelGGL(ref_transpose_u8_wide_kernel, dim3((cols + 127) / 128, (rows + 127) / 128, n_pairs), dim3(256), 0, s, g, cur.level0, (size_t)g.S0,
+                           t.cur0, (size_t)g.S0, rows, cols);
+    else
+        ref_transpose<uint8_t>(g, cur.level0, (size_t)g.S0, t.cur0, (size_t)g.S0, rows, cols, n_pairs, s);
+    Geom gt = g;
+    gt.sel_list = nullptr;
+    gt.sel_count = nullptr;
+    for (int l = 0; l < g.L; ++l) std::swap(gt.lv[l].rows, gt.lv[l].cols);
+    launch_pyramid(gt, Pyramid{t.cur0, t.curu}, n_pairs, s);
 }
 
 // ---- operator level on explicit observations, sums in the order of the observations (the reference's eval on that Obs) --------------
