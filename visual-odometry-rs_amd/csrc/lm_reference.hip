@@ -1267,10 +1267,65 @@ __global__ __launch_bounds__(256) void ref_dense_records_kernel(Geom g, const ui
     for (int j = 2 * wave + c2; j < 64; j += 8)  // column x0 + j, 32 consecutive rows of it (256 bytes per half-wavefront)
         if (x0 + j < cols && y0 + r < rows) out[(size_t)(x0 + j) * rows + y0 + r] = tile[r][j];
 }
+// Level 0 (three quarters of the pixels) when the width is a multiple of 4 and the buffers are 8-byte aligned: FOUR pixels per thread —
+// the rows above, at and below as dwords, the two horizontal neighbours as bytes, the four depths as one 8-byte load: 6 requests per 4
+// pixels instead of 24 (the generic kernel is bound by its request count, not by the 8 bytes it writes per pixel). 128 x 32 tiles.
+__global__ __launch_bounds__(256) void ref_dense_records_level0_kernel(Geom g, const uint8_t* __restrict__ kf0, const uint16_t* __restrict__ depth, Records rec) {
+    __shared__ uint2 tile[32][129];
+    const int pair = select_pair(g, blockIdx.z);
+    if (pair < 0) return;
+    const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 32;
+    const uint8_t* img = kf0 + (size_t)pair * g.S0;
+    const uint16_t* dp = depth + (size_t)pair * g.S0;
+    int n_valid = 0;
+    const int xq = lane & 31, jr = lane >> 5;  // 32 threads x 4 pixels = one 128-pixel row; a wavefront = two rows
+#pragma unroll 2
+    for (int j = 2 * wave + jr; j < 32; j += 8) {
+        const int x = x0 + 4 * xq, y = y0 + j;
+        if (x < cols && y < rows) {
+            const unsigned o = (unsigned)(y * cols + x);
+            const unsigned up = y > 0 ? o - (unsigned)cols : o, dn = y < rows - 1 ? o + (unsigned)cols : o;
+            const uint32_t c4 = *reinterpret_cast<const uint32_t*>(img + o);
+            const uint32_t u4 = *reinterpret_cast<const uint32_t*>(img + up), d4 = *reinterpret_cast<const uint32_t*>(img + dn);
+            const int lft = img[x > 0 ? o - 1u : o], rgt = img[x + 4 < cols ? o + 4u : o + 3u];
+            const uint2 z4 = *reinterpret_cast<const uint2*>(dp + o);
+            const int p[6] = {lft, (int)(c4 & 0xffu), (int)((c4 >> 8) & 0xffu), (int)((c4 >> 16) & 0xffu), (int)(c4 >> 24), rgt};
+            const bool row_border = y == 0 || y == rows - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool border = row_border || x + i == 0 || x + i == cols - 1;  // 1-px border = 0 (gradient.rs:15-33)
+                const int gx = border ? 0 : (p[i + 2] - p[i]) / 2;
+                const int gy = border ? 0 : ((int)((d4 >> (8 * i)) & 0xffu) - (int)((u4 >> (8 * i)) & 0xffu)) / 2;
+                const int dz = (int)(((i < 2 ? z4.x : z4.y) >> (16 * (i & 1))) & 0xffffu);
+                const bool valid = dz != 0;
+                const float iz = g.depth_scale / (float)dz;  // inverse_depth.rs:24-29
+                tile[j][4 * xq + i] = make_uint2(__float_as_uint(iz), slim_pack_tg(p[i + 1], gx, gy) | (valid ? 0x80000000u : 0u));
+                n_valid += valid ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n_valid += __shfl_xor(n_valid, o);
+    if (lane == 0 && n_valid != 0) atomicAdd(&rec.dense_t.n_valid[(size_t)pair * VORS_MAX_LEVELS], n_valid);
+    __syncthreads();
+    uint2* out = rec.dense_t.recs + (size_t)pair * ((size_t)g.S0 + g.upper_stride);
+    const int r = lane & 31, c2 = lane >> 5;
+#pragma unroll 4
+    for (int j = 2 * wave + c2; j < 128; j += 8)  // column x0 + j, 32 consecutive rows of it
+        if (x0 + j < cols && y0 + r < rows) out[(size_t)(x0 + j) * rows + y0 + r] = tile[r][j];
+}
 void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
     if (g.mode != VORS_CANDIDATES_DENSE || !rec.dense_t.recs) return;
     launch_zero_ints(g, rec.dense_t.n_valid, VORS_MAX_LEVELS, n_pairs, s);
-    for (int l = 0; l < g.L; ++l)
+    int first = 0;
+    if (g.lv[0].cols % 4 == 0 && g.S0 % 4 == 0 && ((uintptr_t)kf.level0) % 4 == 0 && ((uintptr_t)depth) % 8 == 0 && !getenv("VORS_REF_RECORDS_GENERIC")) {
+        hipLaunchKernelGGL(ref_dense_records_level0_kernel, dim3((g.lv[0].cols + 127) / 128, (g.lv[0].rows + 31) / 32, n_pairs), dim3(256), 0, s, g, kf.level0,
+                           depth, rec);
+        first = 1;
+    }
+    for (int l = first; l < g.L; ++l)
         hipLaunchKernelGGL(ref_dense_records_kernel, dim3((g.lv[l].cols + 63) / 64, (g.lv[l].rows + 31) / 32, n_pairs), dim3(256), 0, s, g, kf.level0,
                            kf.upper, depth, rec, l);
 }
