@@ -1056,13 +1056,14 @@ static int refw_waves_per_block(int n_pairs) {
     }
     return wpb;
 }
-// Wavefronts per PAIR: a batch that cannot fill the chip with one wavefront per pair gets a workgroup per pair (2, 4 or 8 wavefronts: 1, 3
-// or 7 producers; LDS 2 x P x 7.6 KB). VORS_REF_COOP overrides (0 = one wavefront per pair, 2 / 4 / 8).
+// Wavefronts per PAIR: a batch that cannot fill the chip with one wavefront per pair gets a workgroup per pair (2 .. 8 wavefronts: one owns
+// the chains, the others produce; LDS 2 x P x 7.6 KB). VORS_REF_COOP overrides (0 = one wavefront per pair, 2 .. 8). Measured at 512
+// pairs (3 / 4 / 5 / 6 wavefronts): coarse-to-fine 0.62 / 0.53 / 0.50 / 0.51 ms, DSO 1.08 / 0.86 / 0.81 / 0.84, dense 14.7 / 10.3 / 9.3 / 9.8.
 static int refc_waves_per_pair(int n_pairs) {
-    int w = n_pairs <= 320 ? 8 : (n_pairs <= 1280 ? 4 : 0);
+    int w = n_pairs <= 320 ? 8 : (n_pairs <= 1280 ? 5 : 0);
     if (const char* e = getenv("VORS_REF_COOP")) {
         const int v = atoi(e);
-        if (v == 0 || v == 2 || v == 4 || v == 8) w = v;
+        if (v == 0 || (v >= 2 && v <= 8)) w = v;
     }
     return w;
 }
