@@ -258,7 +258,8 @@ void vors_batch_destroy(vors_batch* b);
 /* Throughput mode for a continuous feed of independent batches: a ring of `depth` batch handles, each on its own internal stream.
  * The tail of a step leaves the GPU partly idle (dependent straggler rounds of the dense LM stage, the last workgroups of the per-pair
  * kernel), its body VALU- or bandwidth-bound: with consecutive steps on different streams the GPU fills one with the other (depth 2 on
- * one MI355X: +6 % dense, +12 % coarse-to-fine frame pairs per second; bench.py `pipelined_two_streams`). Every step is a plain
+ * one MI355X, round-4 driver run: +1.7 % dense frame pairs per second — the dense stage's own side lane absorbed most of what the pipeline used
+ * to recover; round 3 measured +6 % dense, +12 % coarse-to-fine; bench.py `pipelined_two_streams` reports the current figure). Every step is a plain
  * vors_batch_track_pairs — same results bit for bit.
  *   submit: the slot's stream first waits for everything enqueued on hip_stream so far (the inputs, and earlier readers of the output
  *           buffers), then runs the step; nothing is synchronised. Buffers as for vors_batch_track_pairs, and they must stay valid

@@ -196,13 +196,14 @@ def test_fused_full_batch_parity_gate():
 def test_exact_and_fused_gated_against_the_reference_arithmetic_full_batches_all_three_modes():
     """The tail of EXACT and FUSED measured against VORS_ARITH_REFERENCE — the device path that equals the oracle bit for bit
     (tests/test_gpu_reference.py) — at the bench's own sizes: 4096 coarse-to-fine pairs, 4096 DSO pairs (which the round-3 gate left
-    out), 1024 dense pairs, all on the device. REFERENCE is first pinned to the oracle on a 256-pair sample of each batch (bits). Gates:
-    EXACT and FUSED keep the statuses; FUSED puts no more pairs beyond 1e-4 than EXACT does plus a small slack (both differ from the
-    reference path only by the ORDER of the 29 sums — and FUSED by a few ulp per point on the large levels); p99 < 2e-5; nothing lands
-    further than 5e-3 (a forked path ends at most there)."""
+    out), 1024 dense pairs, all on the device. REFERENCE is first pinned to the oracle on the WHOLE of each batch (bits). Gates, relative to
+    what was measured: EXACT and FUSED keep the statuses; each puts no more pairs beyond 1e-4 than the oracle's own summation-order floor
+    (oracle f32 vs its f64-accumulation build on the same batch) + 2 + two standard deviations, per mode and over the three batches
+    together — a regression that doubles the tail is red; p99 < 2e-5; nothing lands further than 5e-3 (a forked path ends at most there)."""
     import torch
     rows, cols, L = 480, 640, 6
     intr = O.scaled_intrinsics(rows, cols)
+    total = {"floor": 0, "EXACT": 0, "FUSED": 0}
     for mode, n in ((0, 4096), (2, 4096), (1, 1024)):
         seed = (BLOCKY if mode == 2 else 0) | 0x5EED0000
         kg, kd, cg, _, _ = V.synth_render_pairs(seed, n, rows, cols, intr)
@@ -216,11 +217,16 @@ def test_exact_and_fused_gated_against_the_reference_arithmetic_full_batches_all
             torch.cuda.synchronize()
             res[arith] = (poses.cpu().numpy(), status.cpu().numpy(), V.decode_stats(stats))
             del b
-        m = 256
-        ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg[:m].cpu().numpy(), kd[:m].cpu().numpy().view(np.uint16),
-                            cg[:m].cpu().numpy(), n_threads=min(os.cpu_count() or 1, m))
+        # the oracle on the WHOLE batch, in f32 (what REFERENCE must equal bit for bit) and with f64 accumulation of the 29 sums: the pairs
+        # on which those two differ by more than 1e-4 are the floor no arithmetic that sums in another order can go below
+        kgn, kdn, cgn = kg.cpu().numpy(), kd.cpu().numpy().view(np.uint16), cg.cpu().numpy()
+        nt = min(os.cpu_count() or 1, n)
+        ocfg = O.make_config(L, intr, candidates_mode=mode)
+        ref = O.track_pairs(ocfg, kgn, kdn, cgn, n_threads=nt)
+        ref64 = O.track_pairs(ocfg, kgn, kdn, cgn, n_threads=nt, variant="acc64")
+        floor = int((np.abs(ref64["poses"] - ref["poses"]).max(axis=1) > POSE_TOL).sum())
         pr, sr, str_ = res[V.ARITH_REFERENCE]
-        assert (pr[:m].view(np.uint32) == ref["poses"].view(np.uint32)).all() and (str_["nb_iter"][:m, :L] == ref["nb_iter"]).all()
+        assert (pr.view(np.uint32) == ref["poses"].view(np.uint32)).all() and (str_["nb_iter"][:, :L] == ref["nb_iter"]).all()
         beyond = {}
         for arith, name in ((V.ARITH_EXACT, "EXACT"), (V.ARITH_FUSED, "FUSED")):
             p, st, stt = res[arith]
@@ -231,5 +237,14 @@ def test_exact_and_fused_gated_against_the_reference_arithmetic_full_batches_all
             print(f"mode {mode}: {name} vs REFERENCE over {n} pairs: beyond 1e-4 {beyond[name]}, p99 {np.quantile(err, 0.99):.2e}, max {err.max():.2e}, "
                   f"LM paths that differ {flips:.0%}")
             assert np.quantile(err, 0.99) < 2e-5 and err.max() < 5e-3
-            assert beyond[name] <= max(3, n // 200), f"mode {mode}: {beyond[name]} {name} pairs beyond 1e-4"
-        assert beyond["FUSED"] <= beyond["EXACT"] + max(2, beyond["EXACT"] // 4), f"mode {mode}: FUSED {beyond['FUSED']} vs EXACT {beyond['EXACT']}"
+            # measured (round 5, three draws of each batch): the counts scatter around the floor like independent Poisson draws of the same
+            # mean (coarse-to-fine 2 / 3 vs 2, DSO 14 / 10 vs 12, dense 0 / 0 vs 0 on this seed) — two standard deviations of slack + 2
+            gate = floor + 2 + 2 * np.sqrt(floor)
+            print(f"mode {mode}: {name} {beyond[name]} beyond 1e-4, oracle f64-accumulation floor {floor}, gate {gate:.1f}")
+            assert beyond[name] <= gate, f"mode {mode}: {beyond[name]} {name} pairs beyond 1e-4, floor {floor}"
+            total[name] += beyond[name]
+        total["floor"] += floor
+    # ... and over the three batches together (9216 pairs), where a doubled tail cannot hide in the counting noise
+    gate = total["floor"] + 2 + 2 * np.sqrt(total["floor"])
+    print(f"all modes: EXACT {total['EXACT']}, FUSED {total['FUSED']}, floor {total['floor']}, gate {gate:.1f}")
+    assert total["EXACT"] <= gate and total["FUSED"] <= gate, total

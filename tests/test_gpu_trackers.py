@@ -1,6 +1,8 @@
 """vors_trackers_*: N sequences advancing in lock-step with the tracker state machine on the device (per-sequence keyframe promotion
 through masked launches) must equal N single vors_tracker handles bit for bit, and the oracle's Tracker within the pose tolerance.
 Reference: src/bin/vors_track.rs:46-62, src/core/track/inverse_compositional.rs:170-240. GPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -173,7 +175,9 @@ def test_config3_shape_640x480_dso_sequences_16_seeds_of_60_frames_vs_oracle():
         else:
             n_out = int((err > POSE_TOL).sum())
             print(f"{name}: {n_out} of {n_seq} sequences leave the 1e-4 band within 60 frames (oracle f32 vs f64 accumulation: {floor}); max {err.max():.2e}")
-            assert n_out <= floor + 3 and err.max() < 5e-3
+            # measured on this seed (round 5): floor 1, EXACT 2, FUSED 2 — one sequence of slack, and the typical sequence stays far inside the band
+            assert n_out <= floor + 1, f"{name}: {n_out} sequences beyond 1e-4, the oracle's own summation-order floor is {floor}"
+            assert np.median(err) < 2e-5 and err.max() < 5e-3
 
 
 def test_config3_at_full_length_600_frame_dso_sequences_reference_arithmetic_bit_identical():
@@ -190,12 +194,20 @@ def test_config3_at_full_length_600_frame_dso_sequences_reference_arithmetic_bit
     assert (stat == ref["status"]).all() and (sw == ref["changed_keyframe"]).all()
     assert (traj.view(np.uint32) == ref["poses"].view(np.uint32)).all(), f"max difference {np.abs(traj - ref['poses']).max():.3e}"
     assert ref["changed_keyframe"].sum() >= 5 * n_seq
+    # FUSED on the same frames, gated against the oracle's own summation-order floor (f32 vs f64 accumulation over the same 600 frames):
+    # a pose is a chain product, so over 600 frames most sequences cross 1e-4 in EITHER arithmetic — what is gated is that FUSED does not
+    # put more sequences outside than the floor plus one, and that nothing drifts further than a forked LM path does (5e-3)
+    ref64 = O.track_sequences(ocfg, gh, dh, n_threads=n_seq, variant="acc64")
+    floor = int((np.abs(ref64["poses"] - ref["poses"]).max(axis=(1, 2)) > POSE_TOL).sum())
     cfg.arithmetic = V.ARITH_FUSED
     trajf, statf, _ = _run_trackers(cfg, frames, n_seq, rows, cols)
     drift = np.abs(trajf - ref["poses"]).max(axis=2)          # [n_seq, frames]
-    print(f"FUSED over 600 frames: {(drift.max(axis=1) > POSE_TOL).sum()} of {n_seq} sequences leave the 1e-4 band; per-frame max drift "
+    n_out = int((drift.max(axis=1) > POSE_TOL).sum())
+    print(f"FUSED over 600 frames: {n_out} of {n_seq} sequences leave the 1e-4 band (oracle f32 vs f64 accumulation: {floor}); per-frame max drift "
           f"at frames 100/300/600: {drift[:, 99].max():.2e} / {drift[:, 299].max():.2e} / {drift[:, 599].max():.2e}")
-    assert (statf == ref["status"]).all() and drift.max() < 2e-2
+    assert (statf == ref["status"]).all()
+    assert n_out <= floor + 1, f"FUSED: {n_out} of {n_seq} sequences beyond 1e-4 over 600 frames, the oracle's own floor is {floor}"
+    assert drift.max() < 5e-3
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["coarse_to_fine", "dense"])
@@ -274,3 +286,44 @@ def test_device_frame_renderer_agrees_with_the_cpu_renderer():
             assert (dg > 0).mean() < 2e-3 and ((dg <= 1) | (seed >> 63 == 1)).all(), f"grey: {(dg > 0).sum()} pixels differ, max {dg.max()}"
             dd = np.abs(d[k].astype(int) - cd.astype(int))
             assert ((d[k] == 0) == (cd == 0)).all() and (dd > 0).mean() < 2e-3 and dd.max() <= 1
+
+
+@pytest.mark.parametrize("mode", [V.CANDIDATES_COARSE_TO_FINE, V.CANDIDATES_DSO], ids=["coarse_to_fine", "dso"])
+def test_64_sequence_tail_of_exact_and_fused_is_the_oracles_own_floor(mode):
+    """bench.py's `sequences_64` statistic (64 sequences x 39 tracked frames, 640x480, 6 levels) as a gate, over TWO draws: the number of
+    sequences whose worst frame lies beyond 1e-4 of the oracle tracker, for EXACT and FUSED, against the oracle's own f32-vs-f64-accumulation
+    count on the same frames (tools/seq_parity.py measures the same over six draws: 9 / 384 coarse-to-fine, 43 / 384 DSO, equal to the floor
+    within counting noise). Gate: beyond <= floor + 2 + 2 sqrt(floor) summed over the draws — a regression that doubles the tail is red;
+    REFERENCE on the same frames: every pose bit-identical."""
+    rows, cols, L, n_seq, n_frames = 480, 640, 6, 64, 40
+    intr = O.scaled_intrinsics(rows, cols)
+    base = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
+    blocky = BLOCKY if mode == V.CANDIDATES_DSO else 0
+    tot = {"floor": 0, "exact": 0, "fused": 0}
+    for d in range(2):
+        rng = np.random.default_rng(11 + d)
+        speed = 0.5 + 1.0 * rng.random(n_seq)
+        sign = rng.choice([-1.0, 1.0], size=(n_seq, 6))
+        frames = [V.synth_render_frames([blocky | (4242 + 1000 * d + s_) for s_ in range(n_seq)], [k] * n_seq,
+                                        [base * sign[s_] * speed[s_] * k for s_ in range(n_seq)], rows, cols, intr) for k in range(n_frames)]
+        gh = np.stack([g.cpu().numpy() for g, _ in frames])
+        dh = np.stack([x.cpu().numpy().view(np.uint16) for _, x in frames])
+        ocfg = O.make_config(L, intr, candidates_mode=mode)
+        nt = min(os.cpu_count() or 1, n_seq)
+        ref = O.track_sequences(ocfg, gh, dh, n_threads=nt)
+        ref64 = O.track_sequences(ocfg, gh, dh, n_threads=nt, variant="acc64")
+        tot["floor"] += int((np.abs(ref64["poses"] - ref["poses"]).max(axis=(1, 2)) > POSE_TOL).sum())
+        for arith, name in ((V.ARITH_REFERENCE, "reference"), (V.ARITH_EXACT, "exact"), (V.ARITH_FUSED, "fused")):
+            cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode, arithmetic=arith)
+            traj, stat, _ = _run_trackers(cfg, frames, n_seq, rows, cols)
+            assert (stat == ref["status"]).all()
+            if arith == V.ARITH_REFERENCE:
+                assert (traj.view(np.uint32) == ref["poses"].view(np.uint32)).all()
+            else:
+                err = np.abs(traj - ref["poses"]).max(axis=(1, 2))
+                tot[name] += int((err > POSE_TOL).sum())
+                assert np.median(err) < 2e-5 and err.max() < 5e-3
+        del frames
+    gate = tot["floor"] + 2 + 2 * np.sqrt(tot["floor"])
+    print(f"mode {mode}: sequences beyond 1e-4 of 128: oracle f64-accumulation floor {tot['floor']}, EXACT {tot['exact']}, FUSED {tot['fused']} (gate {gate:.1f})")
+    assert tot["exact"] <= gate and tot["fused"] <= gate, tot

@@ -658,7 +658,8 @@ vors_status vors_batch_get_points(vors_batch* b, int pair, int level, int capaci
     DeviceGuard guard(b->device);
     HIP_TRY(hipDeviceSynchronize());
     const bool dense = b->g.mode == VORS_CANDIDATES_DENSE;
-    if (!b->kf_level0 || !b->kf_depth) return fail(VORS_ERR_INVALID_ARGUMENT, "no keyframe has been prepared yet");
+    if (!b->kf_level0 || !b->kf_depth)
+        return fail(VORS_ERR_INVALID_ARGUMENT, b->prepared_pairs > 0 ? "keyframe inspection is not available on a trackers-owned batch in the candidate-list modes (the handle keeps records, not frames)" : "no keyframe has been prepared yet");
     if (!dense) {  // sparse modes: compact lists
         int used = 0;
         HIP_TRY(hipMemcpy(&used, b->rec.n_used + (size_t)pair * VORS_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
@@ -711,7 +712,9 @@ vors_status vors_batch_eval_level(vors_batch* b, int pair, int level, const floa
     if (!b || !model7 || !sums29) return fail(VORS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (pair < 0 || pair >= std::min(b->prepared_pairs, b->current_pairs) || level < 0 || level >= b->g.L)
         return fail(VORS_ERR_INVALID_ARGUMENT, "pair/level out of range (pair must be < the n_pairs of the last prepare_keyframes AND track_current)");
-    if (!b->kf_level0 || !b->cur_level0) return fail(VORS_ERR_INVALID_ARGUMENT, "eval_level needs prepare_keyframes and track_current first");
+    if (!b->kf_level0 || !b->cur_level0)
+        return fail(VORS_ERR_INVALID_ARGUMENT, (b->prepared_pairs > 0 && b->current_pairs > 0 && !b->kf_level0) ? "keyframe inspection is not available on a trackers-owned batch in the candidate-list modes (the handle keeps records, not frames)"
+                                                                                                                 : "eval_level needs prepare_keyframes and track_current first");
     if (arithmetic != VORS_ARITH_EXACT && arithmetic != VORS_ARITH_FUSED && arithmetic != VORS_ARITH_REFERENCE)
         return fail(VORS_ERR_INVALID_ARGUMENT, "unknown arithmetic mode");
     DeviceGuard guard(b->device);
@@ -959,6 +962,7 @@ vors_status vors_tracker_track(vors_tracker* t, double depth_time, const uint16_
     if ((st = tracker_upload_gray(t, gray)) != VORS_OK) return st;
     if ((st = trackers_track_lm(t->seq, t->gray.as<uint8_t>(), t->s_main)) != VORS_OK) return st;
     launch_tracker_pack_out(d_pose, d_status, d_kf, d_stats, o, t->s_main);
+    HIP_TRY(hipGetLastError());  // (a failed launch is reported against THIS frame, not against whatever touches the stream next)
     HIP_TRY(hipEventRecord(t->ev_result, t->s_main));
     if ((st = tracker_upload_depth(t, depth)) != VORS_OK) return st;
     if ((st = trackers_promote(t->seq, t->gray.as<uint8_t>(), t->depth.as<uint16_t>(), t->ev_depth, t->s_main)) != VORS_OK) return st;

@@ -91,7 +91,7 @@ VORS_HD Iso renormalize(Iso m) {
 // n = round(x 2/pi) and the polynomial selected by the quadrant — rounded ONCE to f32). That function is NOT the correctly rounded
 // sine (1 % of the arguments in [1e-3, 4] differ from RN(sin x) by one ulp), and the device's ocml sinf is a third function, so the
 // algorithm is restated here, host + device: bit-identical to glibc 2.35's sinf / cosf for EVERY f32 in [2^-12, 4) — with or
-// without FMA contraction of the f64 polynomial (checked exhaustively: tests/test_oracle_kat.py + oracle/sincos_check.c). se3::exp
+// without FMA contraction of the f64 polynomial (checked exhaustively against the platform libm through vors_ref_sincos: tests/test_capi_host.py). se3::exp
 // only calls them with theta / 2 and theta, theta >= 0.01 (se3.rs:82-87); arguments >= 4 rad go to the platform function.
 VORS_HD float ref_sincos_poly(double x, int n) {
     const double x2 = x * x;

@@ -2179,8 +2179,9 @@ void VORS_LAUNCH_LM_TRACK(const Geom& g_in, Pyramid cur, Pyramid kf, const uint1
         (void)hipStreamWaitEvent(s, split.ev_join, 0);
         launch_lm_split_merge(split, split.rounds, s);
     }
-    // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each
-    launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, 256), 1024, 3,
+    // the pairs still iterating (a handful, each with a long serial tail) finish in parallel, one 1024-thread workgroup each (the grid grows with
+    // the batch: a hard batch may leave more than 256 of them, and a workgroup beyond the active list returns at once)
+    launch_lm_track_mode(g, cur, kf, kf_depth, rec, prev_poses7, kf_poses7, out_poses7, out_status, out_stats, std::min(n_pairs, std::max(256, n_pairs / 8)), 1024, 3,
                          split, s);
     launch_lm_track_mode(VORS_LM_MARGS, 2, split, s);
 #undef VORS_LM_MARGS

@@ -604,8 +604,10 @@ class Trackers:
                 raise VorsError(f"expected contiguous [{self.n}, {self.rows}, {self.cols}] frames, got {tuple(t.shape)}")
 
     def init(self, gray, depth):
-        """Config::init for every sequence (frame 0)."""
+        """Config::init for every sequence (frame 0). Only enqueues work on torch's current stream: the frames must stay alive (and unmodified)
+        until that work has run — this object keeps a reference until the next call, like track()."""
         self._check_frames(gray, depth)
+        self._last = (gray, depth)
         _check(lib().vors_trackers_init(self._h, Batch._dp(gray), Batch._dp(depth), Batch._stream()))
 
     def track(self, gray, depth):
