@@ -116,7 +116,7 @@ def lm_counters(args):
     return e
 
 
-LM_STAGE_KERNELS = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel", "lm_ref_track_kernel")
+LM_STAGE_KERNELS = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel", "lm_ref_track_kernel", "lm_ref_track_coop_kernel")
 ONCE_PER_STEP_KERNELS = ("dense_idepth_level1", "keyframe_sparse_kernel", "dso_rounds_kernel")  # launched exactly once per bench step
 
 
@@ -543,7 +543,7 @@ def reference_block(V, args, device, seed0, ring):
                "stages_ms": {"pyramids": round(py, 5), "keyframe": round(kf, 5), "lm": round(lm, 5)},
                "lm_evals_per_pair": round(ev, 2),
                "roofline": {"bound": "hbm", "limited_by": "valu (dependent f32 chains + the reference's per-point expressions)", "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "kernel": "lm_ref_track_kernel",
+                            "unit": "GB/s", "kernel": "lm_ref_track_kernel (+ lm_ref_track_coop_kernel for the pairs handed over)",
                             "achieved": round(lm_bytes / (lm * 1e-3) / 1e9, 2), "frac": round(lm_bytes / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                             "algorithmic_bytes_per_launch": lm_bytes, "kernel_ms_avg": round(lm, 5),
                             "io_only_GBps": round(io * steps / dt / 1e9, 2), "io_only_frac": round(io * steps / dt / 1e9 / HBM_PEAK_GBPS, 5),

@@ -14,7 +14,7 @@ def find(sub, pattern):
     return f[0] if f else None
 
 
-LM_STAGE = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel", "lm_ref_track_kernel")
+LM_STAGE = ("lm_track_kernel", "lm_split_eval_kernel", "lm_split_step_kernel", "lm_ref_track_kernel", "lm_ref_track_coop_kernel")
 ONCE_PER_STEP = ("dense_idepth_level1", "keyframe_sparse_kernel", "dso_rounds_kernel")  # kernels launched exactly once per bench step
 
 
