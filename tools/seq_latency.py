@@ -14,7 +14,7 @@ frames_blocky = [O.synth_frame((1 << 63) | 31337, step * k, rows, cols, intr, fr
 for rep in range(3):
   for mode in (0, 1, 2):
     frames = frames_blocky if mode == 2 else frames_smooth
-    for arith in (1, 0):
+    for arith, aname in ((V.ARITH_FUSED, "fused"), (V.ARITH_REFERENCE, "reference")):
         cfg = V.Config(nb_levels=L, intrinsics=V.INTRINSICS_FR1, candidates_mode=mode, arithmetic=arith)
         vt = cfg.init(0.0, frames[0][1], 0.0, frames[0][0])
         vt.track(0.0, frames[1][1], 0.0, frames[1][0])
@@ -23,4 +23,4 @@ for rep in range(3):
         for k in range(1, n):
             t0 = time.perf_counter(); vt.track(float(k), frames[k][1], float(k), frames[k][0]); ts.append(time.perf_counter()-t0)
         ts=np.array(ts)*1e3
-        print(f"rep {rep} mode {mode} arith {arith}: mean {ts.mean():.3f} ms median {np.median(ts):.3f} p90 {np.quantile(ts,0.9):.3f} max {ts.max():.3f}")
+        print(f"rep {rep} mode {mode} arith {aname}: mean {ts.mean():.3f} ms median {np.median(ts):.3f} p90 {np.quantile(ts,0.9):.3f} max {ts.max():.3f}")

@@ -85,15 +85,22 @@ VORS_G void g_project_uv(const Intr& k, const V3G<F>& p, F* u, F* v) {
     *u = pu / p.z;
     *v = pv / p.z;
 }
+// The two reciprocals of warp_jacobian_at that depend on the level only (`1.0 / fv`, `1.0 / (fu * fv)`, inverse_compositional.rs:330-331):
+// the same two f32 divisions, done once per level instead of once per trip of the evaluation loop (the compiler re-materialises uniform
+// values inside the loop rather than keep them in registers: 22 instructions per trip).
+struct JacRecip {
+    float _fv, _fuv;
+};
+VORS_G JacRecip g_jac_recip(const Intr& k) { return JacRecip{1.0f / k.fv, 1.0f / (k.fu * k.fv)}; }
 // lie.h warp_jacobian_at_fast<FAST> (inverse_compositional.rs:313-341)
 template <bool FAST, class F>
-VORS_G void g_warp_jacobian_at(F gu, F gv, F u, F v, F _z, const IntrFast& kf, F J[6]) {
+VORS_G void g_warp_jacobian_at(F gu, F gv, F u, F v, F _z, const IntrFast& kf, const JacRecip& rc, F J[6]) {
     const Intr& k = kf.k;
     const F a = u - k.cu;
     const F b = v - k.cv;
     const F c = a * k.fv - k.skew * b;
-    const float _fv = 1.0f / k.fv;
-    const float _fuv = 1.0f / (k.fu * k.fv);
+    const float _fv = rc._fv;
+    const float _fuv = rc._fuv;
     J[0] = gu * _z * k.fu;
     J[1] = _z * (gu * k.skew + gv * k.fv);
     J[2] = -_z * (gu * a + gv * b);

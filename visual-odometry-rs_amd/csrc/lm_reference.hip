@@ -57,6 +57,7 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
     const SlimRec* S;
     Intr k;
     FastDiv fu, fv;  // the focal lengths as verified fast divisors (lie.h div_uniform: bit-identical to the IEEE quotient, or `ok` = 0)
+    JacRecip rc;     // 1 / fv, 1 / (fu fv): once per level, in scalar registers (lie_g.h)
     static constexpr bool kTransposed = false;  // the current image is row-major
     typedef SlimRec Raw;
     __device__ __forceinline__ Raw load(int i) const { return S[(unsigned)i]; }
@@ -66,7 +67,9 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
     }
     __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
         *tmpl = (float)(r.tg & 0xffu);
-        warp_jacobian_at_rt((float)slim_gx(r.tg), (float)slim_gy(r.tg), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, IntrFast{k, fu, fv}, J);
+        const float gx = (float)slim_gx(r.tg), gy = (float)slim_gy(r.tg), x = (float)(r.xy & 0xffffu), y = (float)(r.xy >> 16);
+        if (fu.ok) g_warp_jacobian_at<true>(gx, gy, x, y, r.iz, IntrFast{k, fu, fv}, rc, J);  // (uniform branch; = lie.h warp_jacobian_at_rt)
+        else g_warp_jacobian_at<false>(gx, gy, x, y, r.iz, IntrFast{k, fu, fv}, rc, J);
     }
     // two points per lane (lie_g.h); FAST: both focal lengths are verified fast divisors
     template <bool FAST>
@@ -81,7 +84,7 @@ struct RefSlimSrc {  // sparse modes: the 12-byte lists in extract_z's order
         *tmpl = F2{(float)(ra.tg & 0xffu), (float)(rb.tg & 0xffu)};
         const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
         g_warp_jacobian_at<FAST>(F2{(float)slim_gx(ra.tg), (float)slim_gx(rb.tg)}, F2{(float)slim_gy(ra.tg), (float)slim_gy(rb.tg)}, x, y,
-                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, J);
+                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, rc, J);
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* iz, bool* valid) const {
         const SlimRec r = S[(unsigned)i];
@@ -151,6 +154,7 @@ struct RefDenseTSrc {
     uint32_t magic;      // floor(2^32 / rows) + 1: i / rows == __umulhi(i, magic) for i * rows < 2^32 (i < 2^21, rows <= 2^11)
     Intr k;
     FastDiv fu, fv;      // (point2 / jac2; the one-point forms divide)
+    JacRecip rc;
     struct Raw {
         uint32_t xy;   // x | y << 16
         float iz;      // inverse depth (anything when !valid)
@@ -174,7 +178,7 @@ struct RefDenseTSrc {
     }
     __device__ __forceinline__ void jac(const Raw& r, float J[6], float* tmpl) const {
         *tmpl = (float)(r.tgv & 0xffu);
-        warp_jacobian_at((float)slim_gx(r.tgv), (float)slim_gy(r.tgv), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, k, J);
+        g_warp_jacobian_at<false>((float)slim_gx(r.tgv), (float)slim_gy(r.tgv), (float)(r.xy & 0xffffu), (float)(r.xy >> 16), r.iz, IntrFast{k, fu, fv}, rc, J);
     }
     template <bool FAST>
     __device__ __forceinline__ void point2(const Raw& ra, const Raw& rb, V3G<F2>* P, bool* va, bool* vb) const {
@@ -188,7 +192,7 @@ struct RefDenseTSrc {
         *tmpl = F2{(float)(ra.tgv & 0xffu), (float)(rb.tgv & 0xffu)};
         const F2 x{(float)(ra.xy & 0xffffu), (float)(rb.xy & 0xffffu)}, y{(float)(ra.xy >> 16), (float)(rb.xy >> 16)};
         g_warp_jacobian_at<FAST>(F2{(float)slim_gx(ra.tgv), (float)slim_gx(rb.tgv)}, F2{(float)slim_gy(ra.tgv), (float)slim_gy(rb.tgv)}, x, y,
-                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, J);
+                                 F2{ra.iz, rb.iz}, IntrFast{k, fu, fv}, rc, J);
     }
     __device__ __forceinline__ void xy_iz(int i, float* x, float* y, float* izv, bool* valid) const {
         int xi, yi;
@@ -714,6 +718,11 @@ __device__ int refw_solve_level(const Src& src, int n, const RefImg& c, Iso* mod
     return 1;
 }
 
+__device__ __forceinline__ JacRecip ref_jac_recip_uniform(const Intr& k) {
+    const JacRecip r = g_jac_recip(k);
+    return JacRecip{ref_uniform_f(r._fv), ref_uniform_f(r._fuv)};
+}
+
 // Where the points of a level come from (template argument SRC of the kernels below).
 enum { REF_SRC_SLIM = 0, REF_SRC_DENSE_ROWMAJOR = 1, REF_SRC_DENSE_T = 2 };
 
@@ -734,14 +743,14 @@ __device__ __forceinline__ void ref_with_source(const Geom& g, int lvl, int pair
     if constexpr (SRC == REF_SRC_DENSE_T) {
         const RefDensePlanes& t = rec.dense_t;
         RefDenseTSrc src{t.recs + (size_t)pair * ((size_t)g.S0 + g.upper_stride) + (lvl == 0 ? 0 : g.S0 + lg.img_off), lg.rows,
-                         0xffffffffu / (unsigned)lg.rows + 1u, lg.k, lg.fu, lg.fv};
+                         0xffffffffu / (unsigned)lg.rows + 1u, lg.k, lg.fu, lg.fv, ref_jac_recip_uniform(lg.k)};
         f(src, lg.rows * lg.cols);
     } else if constexpr (SRC == REF_SRC_DENSE_ROWMAJOR) {
         RefDenseSrc src{&g, kf0, kfu, kf_depth + (size_t)pair * g.S0, lvl > 0 ? rec.IZ + (size_t)pair * g.slots_total + lg.slot_off : nullptr,
                         pair, lvl, lg.rows, lg.cols, lg.k};
         f(src, lg.rows * lg.cols);
     } else {
-        RefSlimSrc src{rec.S + (size_t)pair * g.slots_total + lg.slot_off, lg.k, lg.fu, lg.fv};
+        RefSlimSrc src{rec.S + (size_t)pair * g.slots_total + lg.slot_off, lg.k, lg.fu, lg.fv, ref_jac_recip_uniform(lg.k)};
         f(src, __builtin_amdgcn_readfirstlane(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + lvl]));
     }
 }
