@@ -390,26 +390,63 @@ __device__ __forceinline__ void refw_consume(const float* block, int nb, int str
     const int lane = threadIdx.x & 63;
     if (lane < RW_NSUM) {
         const float4* row = reinterpret_cast<const float4*>(block + lane * RW_STRIDE);
-        float4 w[WIN];
+        if constexpr (WIN == 8) {
+            // Two register sets of eight reads (half a block each): the eight reads of the NEXT half are requested in one burst, then the 32
+            // additions of the current half run (147 cycles: longer than the LDS latency), so the chain waits for LDS once per call. The
+            // scheduler must not regroup this: left alone it requests a half only after the additions before it (522 cycles per block),
+            // and one read between every four additions is worse still (608) — the chain pays every instruction issued in between.
+            float4 wa[8], wb[8];
 #pragma unroll
-        for (int q = 0; q < WIN; ++q) w[q] = row[q];
-        for (int j = 0; j < nb; ++j) {
-            const float4* nxt = j + 1 < nb ? row + (stride >> 2) : row;  // (after the last block: WIN reads nobody uses)
+            for (int q = 0; q < 8; ++q) wa[q] = row[q];
+            for (int j = 0; j < nb; ++j) {
+                const float4* nxt = j + 1 < nb ? row + (stride >> 2) : row;  // (after the last block: eight reads nobody uses)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 v4 = w[q % WIN];
-                w[q % WIN] = q + WIN < 16 ? row[q + WIN] : nxt[q + WIN - 16];
-                acc = acc + v4.x;
-                acc = acc + v4.y;
-                acc = acc + v4.z;
-                acc = acc + v4.w;
+                for (int q = 0; q < 8; ++q) wb[q] = row[8 + q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc = acc + wa[q].x;
+                    acc = acc + wa[q].y;
+                    acc = acc + wa[q].z;
+                    acc = acc + wa[q].w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wa[q] = nxt[q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc = acc + wb[q].x;
+                    acc = acc + wb[q].y;
+                    acc = acc + wb[q].z;
+                    acc = acc + wb[q].w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                row = nxt;
             }
-            row = nxt;
+        } else {
+            float4 w[WIN];
+#pragma unroll
+            for (int q = 0; q < WIN; ++q) w[q] = row[q];
+            for (int j = 0; j < nb; ++j) {
+                const float4* nxt = j + 1 < nb ? row + (stride >> 2) : row;  // (after the last block: WIN reads nobody uses)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 v4 = w[q % WIN];
+                    w[q % WIN] = q + WIN < 16 ? row[q + WIN] : nxt[q + WIN - 16];
+                    acc = acc + v4.x;
+                    acc = acc + v4.y;
+                    acc = acc + v4.z;
+                    acc = acc + v4.w;
+                }
+                row = nxt;
+            }
         }
     }
 }
 
 #ifdef VORS_REFW_TIMING  // development build (tools/build_ref_variant.sh): shader cycles per phase, summed over all wavefronts
+__device__ unsigned long long refc_prof[10];  // workgroup kernel: producer 0 wait+warp, 1 products, 2 at barriers, 3 groups; wavefront 0: 4 chains, 5 verdict + step, 6 at barriers, 7 chunks; 8 kernel cycles, 9 workgroups
 __device__ unsigned long long refw_prof[8];  // 0 eval cycles (coop: wavefront 0 summing), 1 step cycles, 2 groups of 64 points (coop: barriers), 3 evaluations,
                                              // 4 kernel cycles, 5 wavefronts, 6 coop: verdict + step + publish, 7 coop: wavefront 0 at barriers
 #define REFW_T0(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -916,9 +953,16 @@ struct RefcShared {
 
 // One evaluation at `model` by the whole workgroup. Wavefront 0 returns with the sums in `acc` after having called publish(acc, n_inside)
 // before the last barrier; the producers return after that barrier.
+#ifdef VORS_REFW_TIMING  // (timing build: cycles accumulated in registers, one atomic per wavefront and bucket at the end of the kernel)
+#define REFC_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define REFC_ACC(slot, v) prof[slot] += (unsigned long long)(v)
+#else
+#define REFC_T(v)
+#define REFC_ACC(slot, v)
+#endif
 template <bool HUBER, class Src, class Publish>
 __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* slots, RefcShared& sh, int P, int parity,
-                                          Publish&& publish) {
+                                          Publish&& publish, unsigned long long* prof) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int ngroups = (n + 63) >> 6, nchunks = (ngroups + P - 1) / P;
     const int p = wave - 1;  // producer index
@@ -939,6 +983,7 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
     auto chunk = [&](int ch, const RefTap& tap_cur, RefTap& tap_nxt) {
         if (wave != 0) {
             if (ch < nchunks) {
+                REFC_T(tp0);
                 const int g = ch * P + p;
                 raw_nxt = refw_moved(raw_ahead);
                 {
@@ -948,6 +993,7 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
                     tap_nxt = refw_warp<Src::kTransposed>(Pt, valid && (g + P) * 64 + lane < n, c, model);
                 }
                 raw_ahead = src.load(min((g + 2 * P) * 64 + lane, n - 1));
+                REFC_T(tp1);
                 float J[6], tmpl, pr[RW_NSUM];
                 src.jac(raw_cur, J, &tmpl);
                 refw_products<HUBER, Src::kTransposed>(tap_cur, tmpl, J, c.huber, pr, nullptr);
@@ -957,19 +1003,25 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
                 for (int k = 0; k < RW_NSUM; ++k) block[k * RW_STRIDE + lane] = pr[k];
                 raw_cur = raw_nxt;
                 if (ch == nchunks - 1 && lane == 0 && cnt != 0) atomicAdd(&sh.cnt[parity], cnt);
+                REFC_T(tp2);
+                REFC_ACC(0, tp1 - tp0);  // wait for the previous trip's requests + warp + new requests
+                REFC_ACC(1, tp2 - tp1);  // Jacobian, interpolation, products, LDS stores
+                REFC_ACC(3, 1);
             }
         } else {
-            REFW_T0(t_c0);
+            REFC_T(t_c0);
             if (ch > 0) refw_consume<8>(slots + ((ch - 1) & 1) * P * RW_WORDS, min(P, ngroups - (ch - 1) * P), RW_WORDS, acc);
-            REFW_T0(t_c1);
+            REFC_T(t_c1);
             if (ch == nchunks) publish(acc, sh.cnt[parity]);  // (the producers' counts arrived before the previous barrier)
-            REFW_ADD(0, t_c1 - t_c0);
-            REFW_ADD(6, __builtin_readcyclecounter() - t_c1);
+            REFC_T(t_c2);
+            REFC_ACC(4, t_c1 - t_c0);
+            REFC_ACC(5, t_c2 - t_c1);
+            REFC_ACC(7, 1);
         }
-        REFW_T0(t_b0);
+        REFC_T(t_b0);
         refc_barrier();
-        if (wave == 0) REFW_ADD(7, __builtin_readcyclecounter() - t_b0);
-        if (wave == 0) REFW_ADD(2, 1);
+        REFC_T(t_b1);
+        REFC_ACC(wave != 0 ? 2 : 6, t_b1 - t_b0);
     };
     for (int ch = 0; ch <= nchunks; ch += 2) {
         chunk(ch, tap_a, tap_b);
@@ -1000,6 +1052,7 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
         sh.cnt[1] = 0;
     }
     __syncthreads();
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
     Iso lm_model = ref_iso_uniform(iso_mul(iso_inverse(prev_pose), kf_pose));  // inverse_compositional.rs:177 (every wavefront alike)
@@ -1024,7 +1077,7 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
                         sh.cmd = next;
                         sh.cnt[parity ^ 1] = 0;
                     }
-                });
+                }, prof);
                 parity ^= 1;
                 cmd = __builtin_amdgcn_readfirstlane(sh.cmd);
                 eval_model = ref_iso_uniform(iso_load(sh.model));
@@ -1049,9 +1102,16 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
             break;
         }
     }
+#ifdef VORS_REFW_TIMING
+    if (lane == 0 && wave <= 1)  // wavefront 0 (buckets 4..7) and ONE producer (buckets 0..3)
+        for (int k = (wave ? 0 : 4); k < (wave ? 4 : 8); ++k) atomicAdd(&refc_prof[k], prof[k]);
+    if (threadIdx.x == 0) {
+        atomicAdd(&refc_prof[8], (unsigned long long)(__builtin_readcyclecounter() - t_kernel));
+        atomicAdd(&refc_prof[9], 1ull);
+    }
+#endif
+    (void)prof;
     if (wave != 0) return;  // (no barrier below)
-    REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
-    REFW_ADD(5, 1);
     ref_finish_pair<SRC>(g, pair, kf0, kfu, kf_depth, rec, lm_model, went_well, prev_pose, kf_pose, slots, out_poses7, out_status, out_stats);
 }
 
@@ -1162,6 +1222,14 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
 
 #ifdef VORS_REFW_TIMING
 }  // namespace vors
+extern "C" int vors_debug_refc_profile(unsigned long long out[10], int reset) {  // development build only
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vors::refc_prof), 10 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vors::refc_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int vors_debug_refw_profile(unsigned long long out[8], int reset) {  // development build only
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vors::refw_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
