@@ -1301,6 +1301,16 @@ static void ref_transpose(const Geom& g, const T* src, size_t src_stride, T* dst
     hipLaunchKernelGGL((ref_transpose_kernel<T, TILE>), dim3((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE, n_pairs), dim3(256), 0, s, g, src,
                        src_stride, dst, dst_stride, rows, cols);
 }
+// 8-byte store of data nobody re-reads soon (13 GB of records per 4096 pairs: written once per keyframe, read by the LM stage later):
+// VORS_REF_NT_STORES picks the non-temporal form at compile time (A/B: tools/build_ref_variant.sh).
+__device__ __forceinline__ void ref_store_stream(uint2* p, uint2 v) {
+#ifdef VORS_REF_NT_STORES
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+#else
+    *p = v;
+#endif
+}
 // The keyframe side in one kernel per level: gradient + template of the pixel (device_common.h grad_tmpl_at: gradient.rs:15-33,74-93) and its
 // inverse depth (level 0: scale / depth, inverse_depth.rs:24-29; above: the fused plane) as ONE 8-byte record, read along the rows of the
 // row-major sources, written along the columns (32 x 64 tile through LDS).
@@ -1343,7 +1353,7 @@ __global__ __launch_bounds__(256) void ref_dense_records_kernel(Geom g, const ui
     const int r = lane & 31, c2 = lane >> 5;
 #pragma unroll 2
     for (int j = 2 * wave + c2; j < 64; j += 8)  // column x0 + j, 32 consecutive rows of it (256 bytes per half-wavefront)
-        if (x0 + j < cols && y0 + r < rows) out[(size_t)(x0 + j) * rows + y0 + r] = tile[r][j];
+        if (x0 + j < cols && y0 + r < rows) ref_store_stream(&out[(size_t)(x0 + j) * rows + y0 + r], tile[r][j]);
 }
 // Level 0 (three quarters of the pixels) when the width is a multiple of 4 and the buffers are 8-byte aligned: FOUR pixels per thread —
 // the rows above, at and below as dwords, the two horizontal neighbours as bytes, the four depths as one 8-byte load: 6 requests per 4
@@ -1392,7 +1402,7 @@ __global__ __launch_bounds__(256) void ref_dense_records_level0_kernel(Geom g, c
     const int r = lane & 31, c2 = lane >> 5;
 #pragma unroll 4
     for (int j = 2 * wave + c2; j < 128; j += 8)  // column x0 + j, 32 consecutive rows of it
-        if (x0 + j < cols && y0 + r < rows) out[(size_t)(x0 + j) * rows + y0 + r] = tile[r][j];
+        if (x0 + j < cols && y0 + r < rows) ref_store_stream(&out[(size_t)(x0 + j) * rows + y0 + r], tile[r][j]);
 }
 void launch_ref_dense_planes_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s) {
     if (g.mode != VORS_CANDIDATES_DENSE || !rec.dense_t.recs) return;
