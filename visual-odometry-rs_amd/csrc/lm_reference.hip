@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "device_common.h"
@@ -960,9 +961,16 @@ struct RefcShared {
 #define REFC_T(v)
 #define REFC_ACC(slot, v)
 #endif
+// The records of a producer's first two groups do not change from one evaluation of a level to the next: requested once per level and kept
+// in registers, every later evaluation of the level starts with its warp instead of a memory round trip.
+template <class Src>
+struct RefcFirst {
+    typename Src::Raw r0, r1;
+    bool have;
+};
 template <bool HUBER, class Src, class Publish>
 __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* slots, RefcShared& sh, int P, int parity,
-                                          Publish&& publish, unsigned long long* prof) {
+                                          RefcFirst<Src>& first, Publish&& publish, unsigned long long* prof) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int ngroups = (n + 63) >> 6, nchunks = (ngroups + P - 1) / P;
     const int p = wave - 1;  // producer index
@@ -971,14 +979,19 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
     typename Src::Raw raw_cur = {}, raw_nxt = {}, raw_ahead = {};
     RefTap tap_a = {}, tap_b = {};
     if (wave != 0 && n > 0) {  // the producer's software pipeline over ITS groups p, p + P, ... (refw_eval)
-        raw_cur = src.load(min(p * 64 + lane, n - 1));
+        if (!first.have) {
+            first.r0 = src.load(min(p * 64 + lane, n - 1));
+            first.r1 = src.load(min((p + P) * 64 + lane, n - 1));
+            first.have = true;
+        }
+        raw_cur = first.r0;
         V3 Pt;
         bool valid;
         src.point(raw_cur, &Pt, &valid);
         tap_a = refw_warp<Src::kTransposed>(Pt, valid && p * 64 + lane < n, c, model);
         tap_b = tap_a;
         raw_nxt = raw_cur;
-        raw_ahead = src.load(min((p + P) * 64 + lane, n - 1));
+        raw_ahead = first.r1;
     }
     auto chunk = [&](int ch, const RefTap& tap_cur, RefTap& tap_nxt) {
         if (wave != 0) {
@@ -1069,8 +1082,10 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
         int cmd = REF_LM_EVAL;
         ref_with_source<SRC>(g, lvl, pair, kf0, kfu, kf_depth, rec, [&](const auto& src, int n) {
             Iso eval_model = lm_model;
+            RefcFirst<std::decay_t<decltype(src)>> first;
+            first.have = false;
             do {
-                refc_eval<HUBER>(src, n, c, eval_model, slots, sh, P, parity, [&](float acc, int cnt) {
+                refc_eval<HUBER>(src, n, c, eval_model, slots, sh, P, parity, first, [&](float acc, int cnt) {
                     const int next = ref_lm_advance(s, acc, cnt);
                     if (lane == 0) {
                         iso_store(next == REF_LM_EVAL ? s.cand : s.cur_model, sh.model);
