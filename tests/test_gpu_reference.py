@@ -92,6 +92,9 @@ def test_both_forms_of_the_column_major_sort_give_the_same_lists(monkeypatch, mo
     kg, kd, cg, cd, gt = synth(n, rows, cols, intr, 0x5EED7700, blocky=(mode == 2))
     ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode), kg, kd, cg)
     res = {}
+    # (round 5: the coarse-to-fine mode ranks the keyframe kernel's staged regions directly — rank_regions_kernel, compaction and sort in one
+    # pass; VORS_REF_RANK=0 brings back compact_regions_kernel + sort_colmajor_kernel, whose two forms are then exercised as before)
+    monkeypatch.setenv("VORS_REF_RANK", "0")
     for cap in ("", "0", "1000"):
         if cap:
             monkeypatch.setenv("VORS_REF_SORT_REGCAP", cap)
@@ -100,7 +103,12 @@ def test_both_forms_of_the_column_major_sort_give_the_same_lists(monkeypatch, mo
         b, poses, status, stats, _ = run_batch(vcfg(L, intr, mode), kg, kd, cg)
         assert_pairs_identical(ref, poses, status, stats, L, f"sort form {cap or 'default'}")
         res[cap] = [[b.points(p, l)[0] for l in range(L)] for p in range(n)]
-    for cap in ("0", "1000"):
+    monkeypatch.delenv("VORS_REF_SORT_REGCAP", raising=False)
+    monkeypatch.delenv("VORS_REF_RANK", raising=False)
+    b, poses, status, stats, _ = run_batch(vcfg(L, intr, mode), kg, kd, cg)
+    assert_pairs_identical(ref, poses, status, stats, L, "default (coarse-to-fine: ranked straight from the staged regions)")
+    res["rank"] = [[b.points(p, l)[0] for l in range(L)] for p in range(n)]
+    for cap in ("0", "1000", "rank"):
         for p in range(n):
             for l in range(L):
                 assert (res[cap][p][l] == res[""][p][l]).all(), (cap, p, l)

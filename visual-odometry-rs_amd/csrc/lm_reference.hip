@@ -7,23 +7,27 @@
 // i.e. one rounding for the product, one for the addition, no FMA, outside points skipped. The accept / stop comparisons of the LM loop
 // (lm_optimizer.rs:144,179) are decided at ties, so ANY other order of these additions forks the loop in ~60 % of the pairs and leaves
 // a 0.05-0.4 % tail beyond 1e-4. The EXACT arithmetic already gives bit-identical per-point residuals and Jacobians;
-// this file adds the order:
+// this file adds the order (round 5: as a throughput mode; it is the boundary's DEFAULT arithmetic, include/vors_hip.h):
 //
-//   * candidate lists in column-major order: sort_colmajor_kernel re-orders every (pair, level) list of the sparse modes by the key
-//     x * rows + y (an LDS bitmap of the level + prefix popcounts = the rank of each candidate: keys are unique); the dense mode
-//     enumerates pixels column by column;
-//   * a PRODUCER / CONSUMER workgroup per frame pair: three wavefronts evaluate the points of a chunk in the reference's per-point
-//     arithmetic and leave (r, J[6]) per point, IN LIST ORDER, in LDS; meanwhile 28 lanes of the fourth wavefront — one per sum:
-//     sum r^2, 6 g, 21 H — walk the previous chunk point by point: two LDS reads, one multiplication, one addition. An outside point
-//     is stored as zeros: adding +0 is exact (a running sum that starts at +0 never becomes -0), so it equals skipping it.
+//   * candidate lists in column-major order: coarse-to-fine — rank_regions_kernel packs AND orders the keyframe kernel's staged regions in
+//     one pass (an LDS bitmap of the level, rank = set bits below the key x * rows + y: keys are unique); DSO — sort_colmajor_kernel
+//     re-orders the Morton-sorted lists the same way; dense — 8-byte column-major records written once per keyframe
+//     (ref_dense_records_*_kernel), so that point i of the reference's enumeration is record i;
+//   * ONE WAVEFRONT per frame pair (lm_ref_track_kernel): every lane evaluates one or two points in the reference's per-point arithmetic
+//     (lie.h, lie_g.h) and stores the 28 PRODUCTS the reference adds — r * r, jac * r, jac * jac^T, each rounded once — product-major into
+//     the wavefront's own 7.6 KB of LDS; lane k < 28 then walks row k with 64 dependent v_add_f32: the chain the reference performs for
+//     sum k. An outside point stores +0: adding +-0 is exact, so it equals skipping the point. No barrier; the records of the trip after
+//     next and the taps of the next trip are requested before a trip's chains run (refw_eval / refw_eval2);
+//   * small batches, single trackers and the stragglers of a large batch: a WORKGROUP per pair (lm_ref_track_coop_kernel) — one wavefront
+//     owns the chains and the LM state machine (ref_lm_advance), the others produce product blocks; the same chains, bit for bit;
 //   * step() with the IEEE Cholesky of lie.h and sinf / cosf as glibc computes them (lie.h ref_sinf / ref_cosf), the optical-flow sum
 //     of the keyframe test in list order as well (inverse_compositional.rs:213-221).
 //
 // Result: the device follows the oracle's LM path decision for decision — iteration counts equal at every level, poses bit-identical
-// (tests/test_gpu_reference.py asserts equality, not a tolerance). Cost: the chain of dependent additions (~5 cycles per point and
-// evaluation) — 2-3x the time of EXACT. It is the parity anchor, not the throughput mode.
+// (tests/test_gpu_reference.py asserts equality, not a tolerance). Cost against FUSED at 4096 pairs: 1.3x (coarse-to-fine, DSO), 3.8x
+// (dense); what binds it is the number of VALU instructions of the reference's own per-point expressions.
 //
-// Compile with -ffp-contract=off (no FMA may be formed from the consumer's multiply + add).
+// Compile with -ffp-contract=off (no FMA may be formed from a product and the addition that follows it).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
