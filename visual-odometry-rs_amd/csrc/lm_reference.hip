@@ -1225,7 +1225,7 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         int hw = 4;
         if (const char* e = getenv("VORS_REF_HANDOFF_WAVES")) {
             const int v = atoi(e);
-            if (v == 2 || v == 4 || v == 8) hw = v;
+            if (v >= 2 && v <= 8) hw = v;
         }
         const size_t lds = (size_t)2 * (hw - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
 #define VORS_REF_LAUNCH(K)                                                                                                                  \
