@@ -665,7 +665,23 @@ __device__ __forceinline__ void ref_lm_begin(RefLm& s, const Iso& model) {
 }
 // `acc` / `cnt`: sums and inside count of the evaluation of s.cand. Returns REF_LM_EVAL (evaluate s.cand next), REF_LM_DONE (the level's
 // result is s.cur_model) or REF_LM_FAIL (step() failed: "Error at Cholesky decomposition of hessian", lm_optimizer.rs:131-133).
-__device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt) {
+// The candidate a REJECTED evaluation leads to does not depend on that evaluation: step() of the kept state with lm_coef * 10
+// (lm_optimizer.rs:164-169). Half of all evaluations are rejected (bench.py: 34 evaluations per pair, 17 of them accepted or initial), so
+// whoever has idle time while an evaluation runs (wavefront 0 of the workgroup kernel, during the producers' first chunk) computes it
+// ahead — the same step() call on the same inputs, taken instead of computed when the verdict is "rejected".
+struct RefLmAhead {
+    Iso cand;
+    bool ok, valid;
+};
+__device__ __forceinline__ RefLmAhead ref_lm_step_ahead(const RefLm& s) {
+    RefLmAhead a;
+    a.valid = s.started && !(s.nb_iter > 20);  // (a rejected evaluation with too many iterations stops the level instead)
+    a.ok = false;
+    a.cand = s.cand;
+    if (a.valid) a.ok = refw_step(s.kept, s.cur_model, s.lm_coef * 10.0f, &a.cand);
+    return a;
+}
+__device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt, const RefLmAhead* ahead = nullptr) {
     const float energy = refw_lane(acc, 0) / (float)cnt;  // energy_sum / residuals.len(): 0 / 0 = NaN like the reference
     if (!s.started) {  // init: lm_optimizer.rs:113-118
         s.started = true;
@@ -677,6 +693,11 @@ __device__ __forceinline__ int ref_lm_advance(RefLm& s, float acc, int cnt) {
         if (energy > s.cur_energy) {  // Err(energy)
             if (too_many_iterations) return REF_LM_DONE;
             s.lm_coef *= 10.0f;
+            if (ahead && ahead->valid) {  // step() of exactly this state was computed while the evaluation ran
+                s.nb_iter += 1;
+                s.cand = ahead->cand;
+                return ahead->ok ? REF_LM_EVAL : REF_LM_FAIL;
+            }
         } else {
             const float d_energy = s.cur_energy - energy;
             s.n_full += 1;
@@ -972,9 +993,9 @@ struct RefcFirst {
     typename Src::Raw r0, r1;
     bool have;
 };
-template <bool HUBER, class Src, class Publish>
+template <bool HUBER, class Src, class Publish, class Ahead>
 __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c, const Iso& model, float* slots, RefcShared& sh, int P, int parity,
-                                          RefcFirst<Src>& first, Publish&& publish, unsigned long long* prof) {
+                                          RefcFirst<Src>& first, Publish&& publish, Ahead&& ahead, unsigned long long* prof) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int ngroups = (n + 63) >> 6, nchunks = (ngroups + P - 1) / P;
     const int p = wave - 1;  // producer index
@@ -1027,6 +1048,7 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
             }
         } else {
             REFC_T(t_c0);
+            if (ch == 0) ahead();  // nothing to sum yet: the producers are on their first chunk
             if (ch > 0) refw_consume<8>(slots + ((ch - 1) & 1) * P * RW_WORDS, min(P, ngroups - (ch - 1) * P), RW_WORDS, acc);
             REFC_T(t_c1);
             if (ch == nchunks) publish(acc, sh.cnt[parity]);  // (the producers' counts arrived before the previous barrier)
@@ -1046,7 +1068,11 @@ __device__ __forceinline__ void refc_eval(const Src& src, int n, const RefImg& c
     }
 }
 
-template <bool HUBER, int SRC>
+// AHEAD: wavefront 0 computes the rejected-case candidate while the producers are on an evaluation's first chunk (ref_lm_step_ahead). Its
+// second copy of step() costs ~14 registers — one wavefront slot per SIMD, which the mid-sized batches (two workgroups of five wavefronts per
+// CU) need and the small ones (one workgroup of eight per CU) do not: measured 128 pairs 0.397 -> 0.386 ms, one tracker 0.335 -> 0.312 ms
+// per frame, but 512 pairs 0.477 -> 0.74 ms when it is on everywhere.
+template <bool HUBER, int SRC, bool AHEAD>
 __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const uint8_t* __restrict__ cur0, const uint8_t* __restrict__ curu,
                                                                 const uint8_t* __restrict__ kf0, const uint8_t* __restrict__ kfu,
                                                                 const uint16_t* __restrict__ kf_depth, Records rec,
@@ -1089,14 +1115,16 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
             RefcFirst<std::decay_t<decltype(src)>> first;
             first.have = false;
             do {
+                RefLmAhead ahead;
+                ahead.valid = false;
                 refc_eval<HUBER>(src, n, c, eval_model, slots, sh, P, parity, first, [&](float acc, int cnt) {
-                    const int next = ref_lm_advance(s, acc, cnt);
+                    const int next = ref_lm_advance(s, acc, cnt, &ahead);
                     if (lane == 0) {
                         iso_store(next == REF_LM_EVAL ? s.cand : s.cur_model, sh.model);
                         sh.cmd = next;
                         sh.cnt[parity ^ 1] = 0;
                     }
-                }, prof);
+                }, [&]() { if constexpr (AHEAD) ahead = ref_lm_step_ahead(s); }, prof);
                 parity ^= 1;
                 cmd = __builtin_amdgcn_readfirstlane(sh.cmd);
                 eval_model = ref_iso_uniform(iso_load(sh.model));
@@ -1176,6 +1204,19 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
             else VORS_REF_LAUNCH((KERNEL<false, REF_SRC_SLIM>));                                               \
         }                                                                                                      \
     } while (0)
+#define VORS_REF_DISPATCH_COOP(AH)                                                                              \
+    do {                                                                                                       \
+        if (src == REF_SRC_DENSE_T) {                                                                          \
+            if (huber) VORS_REF_LAUNCH((lm_ref_track_coop_kernel<true, REF_SRC_DENSE_T, AH>));                 \
+            else VORS_REF_LAUNCH((lm_ref_track_coop_kernel<false, REF_SRC_DENSE_T, AH>));                      \
+        } else if (src == REF_SRC_DENSE_ROWMAJOR) {                                                            \
+            if (huber) VORS_REF_LAUNCH((lm_ref_track_coop_kernel<true, REF_SRC_DENSE_ROWMAJOR, AH>));          \
+            else VORS_REF_LAUNCH((lm_ref_track_coop_kernel<false, REF_SRC_DENSE_ROWMAJOR, AH>));               \
+        } else {                                                                                               \
+            if (huber) VORS_REF_LAUNCH((lm_ref_track_coop_kernel<true, REF_SRC_SLIM, AH>));                    \
+            else VORS_REF_LAUNCH((lm_ref_track_coop_kernel<false, REF_SRC_SLIM, AH>));                         \
+        }                                                                                                      \
+    } while (0)
     if (coop) {
         const size_t lds = (size_t)2 * (coop - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
         // (a launch may ask for more than 64 KB of dynamic LDS only after the kernel has been told so; per device, hence not cached in a static)
@@ -1185,7 +1226,8 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         hipLaunchKernelGGL(K, dim3(n_pairs), dim3(64 * coop), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
                            kf_poses7, out_poses7, out_status, out_stats, n_pairs, 0);                                                      \
     } while (0)
-        VORS_REF_DISPATCH(lm_ref_track_coop_kernel);
+        if (coop >= 8) VORS_REF_DISPATCH_COOP(true);
+        else VORS_REF_DISPATCH_COOP(false);
 #undef VORS_REF_LAUNCH
         return;
     }
@@ -1234,7 +1276,7 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         hipLaunchKernelGGL(K, dim3(n_pairs - ho_after), dim3(64 * hw), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
                            kf_poses7, out_poses7, out_status, out_stats, n_pairs, 1);                                                      \
     } while (0)
-        VORS_REF_DISPATCH(lm_ref_track_coop_kernel);
+        VORS_REF_DISPATCH_COOP(false);
 #undef VORS_REF_LAUNCH
     }
 }
@@ -1291,6 +1333,7 @@ void launch_lm_eval_level_reference(const Geom& g, Pyramid cur, Pyramid kf, cons
     VORS_REF_DISPATCH(lm_ref_eval_level_kernel);
 #undef VORS_REF_LAUNCH
 #undef VORS_REF_DISPATCH
+#undef VORS_REF_DISPATCH_COOP
 }
 
 // ------------------------------------------------------------------------------------------------------------
