@@ -324,7 +324,10 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->rec.IZ, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.V, slots, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->rec.n_used, np * VORS_MAX_LEVELS, &b->bytes);
-        if (g.arith == VORS_ARITH_REFERENCE) {  // column-major copies of what the LM kernel reads (engine.h RefDensePlanes)
+        // column-major records + current pyramid (engine.h RefDensePlanes). Their index arithmetic (i / rows through one multiply-high,
+        // lm_reference.hip RefDenseTSrc) is exact while pixels x rows < 2^32 — up to 1920x1080 and beyond; larger frames keep the gathering
+        // source on the row-major planes (correct, slow).
+        if (g.arith == VORS_ARITH_REFERENCE && (unsigned long long)g.S0 * (unsigned long long)g.lv[0].rows < (1ull << 32)) {
             RefDensePlanes& t = b->rec.dense_t;
             if (e == hipSuccess) e = dmalloc(&t.recs, np * ((size_t)g.S0 + g.upper_stride), &b->bytes);
             if (e == hipSuccess) e = dmalloc(&t.n_valid, np * VORS_MAX_LEVELS, &b->bytes);
