@@ -539,6 +539,8 @@ def reference_block(V, args, device, seed0, ring):
         kf = float(w.batch.kernel_times("keyframe")[-steps:].mean())
         py = float((w.batch.kernel_times("pyramid_keyframe")[-steps:] + w.batch.kernel_times("pyramid_current")[-steps:]).mean())
         lm_bytes = lmb + 32 * a.pairs
+        cnt = live_counters(a, mode) if not args.no_pmc else {}   # three short rocprofv3 passes of this mode in the REFERENCE arithmetic
+        tr = cnt.get("traffic_bytes")
         blk = {"value": round(a.pairs * steps / dt, 2), "unit": "frame-pairs/s", "pairs_per_gpu": a.pairs, "ms_per_step": round(dt / steps * 1e3, 4),
                "stages_ms": {"pyramids": round(py, 5), "keyframe": round(kf, 5), "lm": round(lm, 5)},
                "lm_evals_per_pair": round(ev, 2),
@@ -546,6 +548,9 @@ def reference_block(V, args, device, seed0, ring):
                             "unit": "GB/s", "kernel": "lm_ref_track_kernel (+ lm_ref_track_coop_kernel for the pairs handed over)",
                             "achieved": round(lm_bytes / (lm * 1e-3) / 1e9, 2), "frac": round(lm_bytes / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                             "algorithmic_bytes_per_launch": lm_bytes, "kernel_ms_avg": round(lm, 5),
+                            "traffic": tr, "traffic_source": cnt.get("source"), "traffic_over_algorithmic": (round(tr / lm_bytes, 3) if tr else None),
+                            "memory_side_frac": (round(tr / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr else None),
+                            "valu_instructions_per_launch": cnt.get("sq_insts_valu"),
                             "io_only_GBps": round(io * steps / dt / 1e9, 2), "io_only_frac": round(io * steps / dt / 1e9 / HBM_PEAK_GBPS, 5),
                             "whole_job_frac": round((io + lmb) * steps / dt / 1e9 / HBM_PEAK_GBPS, 5)}}
         del w
