@@ -103,6 +103,9 @@ const char* vors_last_error(void);
 int vors_device_count(void);
 /* Peak shader clock (hipDeviceAttributeClockRate, kHz), compute units and device memory of a HIP device (all nullable). */
 vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes);
+/* Self-check of the DSO selector's gradient-magnitude root (dso_kernels.hip isqrt_floor_u16: the hardware square root + 0.001, truncated):
+ * the number of arguments 0 .. 65535 for which it differs from floor(sqrt(n)) on this device — 0 on gfx950 (tests/test_gpu_parity.py). */
+vors_status vors_selfcheck_isqrt(int* mismatches);
 /* ABI version of this header: bump on any signature change. */
 int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_grad_evals, vors_batch_eval_level
                               * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version, vors_pipeline_*, vors_device_info,

@@ -468,6 +468,56 @@ def test_dso_candidates_vs_oracle(rows, cols, L, n):
     assert np.abs(poses[ok] - ref["poses"][ok]).max(initial=0) < POSE_TOL
 
 
+def test_dso_gradient_magnitude_root_is_exact_for_every_argument():
+    """gradient.rs:49-65 / candidates_dso.rs:42: sqrt(squared_norm) as u16. The selector takes it as (int)(v_sqrt_f32(n) + 0.001) — four
+    instructions instead of the corrected root's twelve, 16 pixels per thread; every argument a u8 image can produce (and all of 0 .. 65535)
+    must give floor(sqrt(n))."""
+    assert V.selfcheck_isqrt() == 0
+
+
+@pytest.mark.parametrize("first_maxima", ["0", "1"])
+def test_dso_first_round_block_maxima_from_the_first_pass(first_maxima, monkeypatch):
+    """VORS_DSO_FIRST_MAXIMA=1: the gradient-magnitude pass also leaves the 4 x 4 block maxima of the first selection round (first maximum
+    in column-major order, dso.rs:192-222) and the rounds kernel skips that pass; same masks as the oracle either way (480 x 640 goes
+    through the strip kernel; 60 x 80 has partial regions)."""
+    monkeypatch.setenv("VORS_DSO_FIRST_MAXIMA", first_maxima)
+    for rows, cols, L, n in ((480, 640, 6, 2), (60, 80, 3, 2), (250, 336, 4, 2)):
+        intr = O.scaled_intrinsics(rows, cols)
+        kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=BLOCKY | 0x5EED1300, intr=intr)
+        b, poses, status, stats, _ = run_batch(vcfg(L, intr, 2), kg, kd, cg)
+        for p in range(n):
+            omask, bs = O.dso_mask(kg[p])
+            xy, iz, jac, tm = b.points(p, 0)
+            mask = np.zeros((rows, cols), np.uint8)
+            mask[xy[:, 1], xy[:, 0]] = 1
+            assert (mask == (omask & (kd[p] != 0))).all(), f"{cols}x{rows}, pair {p} (rounds {bs})"
+
+
+@pytest.mark.parametrize("form", [{}, {"VORS_DSO_SCAN": "1"}, {"VORS_DSO_PLANES": "1"}], ids=["pick_lists", "stamp_scan", "mask_planes"])
+def test_dso_pick_stamps_stay_valid_over_many_keyframes_of_one_handle(form, monkeypatch):
+    """The pick stamps carry the epoch of their selection (1 .. 15 per pair) and the stamp plane is cleared only when a pair's epoch wraps
+    — not per keyframe. 34 different keyframes through ONE handle (two wraps), in every form that reads the stamps (the scan of the stamp
+    plane, the mask planes) and in the default one (pick lists): the level-0 candidates are the oracle's mask every time. (Per-pair epochs under
+    keyframe changes of a subset of the pairs: the DSO sequence tests of test_gpu_trackers.py.)"""
+    import torch
+    for k, v in form.items():
+        monkeypatch.setenv(k, v)
+    rows, cols, L, n = 120, 160, 4, 3
+    intr = O.scaled_intrinsics(rows, cols)
+    b = V.Batch(vcfg(L, intr, 2), n, rows, cols)
+    poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for it in range(34):
+        kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=BLOCKY | (0x5EED1200 + 16 * it), intr=intr)
+        b.track_pairs(*to_dev(kg, kd, cg), poses, status)
+        torch.cuda.synchronize()
+        for p in range(n):
+            omask, bs = O.dso_mask(kg[p])
+            xy, iz, jac, tm = b.points(p, 0)
+            mask = np.zeros((rows, cols), np.uint8)
+            mask[xy[:, 1], xy[:, 0]] = 1
+            assert (mask == (omask & (kd[p] != 0))).all(), f"keyframe {it}, pair {p} (rounds {bs})"
+
+
 def test_dense_with_unaligned_device_buffers():
     """Device buffers that are not 16-byte aligned must fall back from the wide-load quad source to the per-pixel source and
     give the same poses."""

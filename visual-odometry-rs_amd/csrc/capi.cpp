@@ -251,6 +251,16 @@ int vors_device_count(void) {
 }
 int vors_abi_version(void) { return 5; }
 
+vors_status vors_selfcheck_isqrt(int* mismatches) {
+    vors_status st = require_device();
+    if (st != VORS_OK) return st;
+    if (!mismatches) return fail(VORS_ERR_INVALID_ARGUMENT, "mismatches is null");
+    const int n = vors::count_isqrt_u16_mismatches(nullptr);
+    if (n < 0) return fail(VORS_ERR_HIP, "isqrt self-check could not run");
+    *mismatches = n;
+    return VORS_OK;
+}
+
 vors_status vors_device_info(int device, int* clock_khz, int* compute_units, uint64_t* memory_bytes) {
     vors_status st = require_device();
     if (st != VORS_OK) return st;
@@ -377,6 +387,7 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         if (e == hipSuccess) e = dmalloc(&b->dso.mask1, np * b->dso.mask_stride, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.picked, np * g.S0, &b->bytes);
         if (e == hipSuccess) e = dmalloc(&b->dso.state, np, &b->bytes);
+        if (e == hipSuccess) e = hipMemset(b->dso.state, 0, np * sizeof(DsoState));  // epoch 0: the first selection clears the stamp plane
         // picks of one selection round: every block of the first round's three levels at most (a later round with smaller blocks may
         // exceed it: the list then overflows and the pair falls back to the scan of the stamp plane)
         b->dso.list_cap = (g.S0 / 16 + g.S0 / 64 + g.S0 / 256 + 1024 + 3) & ~3;

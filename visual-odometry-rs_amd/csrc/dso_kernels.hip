@@ -30,8 +30,8 @@ __device__ __forceinline__ uint64_t dso_splitmix64(uint64_t x) {
 
 // Per 32x32 region (one WAVEFRONT, four regions per workgroup, no workgroup barrier): gradient magnitude
 // (sqrt(((gx^2 + gy^2) / 4) as u16 as f32)) as u16, border 0 (gradient.rs:49-65, candidates_dso.rs:42), written to the gmag plane, and
-// the region median sorted[len / 2] through a wave-private 256-bin histogram in LDS (dso.rs:307-325). Also clears the pick stamps of the
-// previous keyframe. A lane owns 4 consecutive pixels in each of 4 rows (row = lane / 8 + 8 * pass).
+// the region median sorted[len / 2] through a wave-private 256-bin histogram in LDS (dso.rs:307-325). Also clears the pick stamps when the
+// pair's stamp epoch wraps (dso_next_epoch below). A lane owns 4 consecutive pixels in each of 4 rows (row = lane / 8 + 8 * pass).
 // floor(sqrt(n)) for 0 <= n < 2^22, exactly: the hardware square root (1 ulp) truncated, then corrected by at most one. Equals
 // (sqrtf((float)n) as u16) of gradient.rs:49-65 — the correctly rounded root of an integer below 2^22 never rounds up to the next integer
 // (k - sqrt(k^2 - 1) > 1 / (2k) >> half an ulp of k).
@@ -40,6 +40,29 @@ __device__ __forceinline__ int isqrt_floor(int n) {
     s -= (s * s > n) ? 1 : 0;
     s += ((s + 1) * (s + 1) <= n) ? 1 : 0;
     return s;
+}
+// Pick stamps carry the EPOCH of their selection (1 .. 15, DsoState::epoch, per pair) in the high nibble: a stamp of an earlier keyframe is
+// recognisably stale, so the 307 k-byte stamp plane is cleared once per 15 selections (when the epoch wraps) instead of per keyframe
+// (1.26 GB of stores per 4096 pairs in the first pass).
+__device__ __forceinline__ int dso_next_epoch(int prev) { return (int)((unsigned)prev % 15u) + 1; }
+// The same for 0 <= n < 2^16 in four instructions: sqrt(n) of a non-square n is at least 1 / (2 sqrt(n)) > 0.0019 below the next integer,
+// the hardware root is within 1 ulp (3e-5 at 256), so adding 0.001 lifts an exact root that came out one ulp low over its integer and
+// never lifts anything else (checked for every n by vors_debug_isqrt_mismatches / tests/test_gpu_parity.py).
+__device__ __forceinline__ int isqrt_floor_u16(int n) { return (int)(__builtin_amdgcn_sqrtf((float)n) + 0.001f); }
+__global__ void isqrt_check_kernel(int* mismatches) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < (1 << 16) && isqrt_floor_u16(n) != isqrt_floor(n)) atomicAdd(mismatches, 1);
+}
+int count_isqrt_u16_mismatches(hipStream_t s) {  // every argument of the four-instruction root against the corrected one (must be 0)
+    int* flag = nullptr;
+    int host = -1;
+    if (hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)) != hipSuccess) return -1;
+    if (hipMemsetAsync(flag, 0, sizeof(int), s) == hipSuccess) {
+        hipLaunchKernelGGL(isqrt_check_kernel, dim3((1 << 16) / 256), dim3(256), 0, s, flag);
+        if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) host = -1;
+    }
+    (void)hipFree(flag);
+    return host;
 }
 __device__ __forceinline__ void dso_hist_add(int* hist, int v, bool active) {
     // most of a region usually shares one value (flat image areas): the first active lane's value is added once for the whole
@@ -67,6 +90,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
     const uint8_t* img = kf0 + (size_t)pair * g.S0;
     uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
     uint8_t* pk = ws.picked + (size_t)pair * g.S0;
+    const bool clear = dso_next_epoch(ws.state[pair].epoch) == 1;  // (the rounds kernel behind this one advances the epoch)
     const int lx0 = (lane & 7) * 4, x0 = rj * DSO_REGION + lx0;
     int out[4][4];
     if (wide) {  // cols % 4 == 0 and 4-byte aligned planes: a lane's 4 pixels are one dword in every plane
@@ -92,13 +116,13 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
             for (int k = 0; k < 4; ++k) {
                 const int gx = row[k + 2] - row[k], gy = (int)((dn[ps] >> (8 * k)) & 0xff) - (int)((up[ps] >> (8 * k)) & 0xff);
                 const int x = x0 + k;
-                out[ps][k] = (in && x > 0 && x < cols - 1) ? isqrt_floor((gx * gx + gy * gy) / 4) : 0;  // <= 180
+                out[ps][k] = (in && x > 0 && x < cols - 1) ? isqrt_floor_u16((gx * gx + gy * gy) / 4) : 0;  // <= 180
             }
             if (own) {
                 const size_t o = (size_t)y * cols + x0;
                 *reinterpret_cast<uint32_t*>(gm + o) =
                     (uint32_t)out[ps][0] | ((uint32_t)out[ps][1] << 8) | ((uint32_t)out[ps][2] << 16) | ((uint32_t)out[ps][3] << 24);
-                *reinterpret_cast<uint32_t*>(pk + o) = 0u;
+                if (clear) *reinterpret_cast<uint32_t*>(pk + o) = 0u;
             }
         }
     } else {
@@ -114,10 +138,10 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
                     if (x > 0 && y > 0 && x < cols - 1 && y < rows - 1) {
                         const uint8_t* p = img + o;
                         const int gx = (int)p[1] - (int)p[-1], gy = (int)p[cols] - (int)p[-cols];
-                        v = isqrt_floor((gx * gx + gy * gy) / 4);
+                        v = isqrt_floor_u16((gx * gx + gy * gy) / 4);
                     }
                     gm[o] = (uint8_t)v;
-                    pk[o] = 0;
+                    if (clear) pk[o] = 0;
                 }
                 out[ps][k] = v;
             }
@@ -154,6 +178,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_kernel(Geom g, const u
 // load / store instruction of a wavefront moves eight full 128-byte lines instead of eight quarter lines (the per-region form above spends
 // 1.2 of its 1.57 ms per 4096 pairs on its 20 narrow loads per lane). The four region histograms are shared by the workgroup: a thread
 // adds its 16 values run by run (flat areas: one LDS atomic per thread); then wavefront w extracts the median of region w.
+template <bool MAXIMA>
 __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws) {
     __shared__ int s_hist[4][256];
     const int pair = select_pair(g, blockIdx.y);
@@ -166,6 +191,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, c
     const uint8_t* img = kf0 + (size_t)pair * g.S0;
     uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
     uint8_t* pk = ws.picked + (size_t)pair * g.S0;
+    const bool clear = dso_next_epoch(ws.state[pair].epoch) == 1;
     const int x0 = sj * 128 + (lane & 7) * 16, y = ri * DSO_REGION + wave * 8 + (lane >> 3);
     const bool own = x0 < cols && y < rows;  // (cols % 16 == 0: a thread's 16 pixels are all inside or all outside)
     const int reg = (lane & 7) >> 1;         // region of the strip this thread's pixels belong to
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, c
                 const int gx = row[k + 2] - row[k];
                 const int gy = (int)((d[k >> 2] >> (8 * (k & 3))) & 0xff) - (int)((u[k >> 2] >> (8 * (k & 3))) & 0xff);
                 const int x = x0 + k;
-                out[k] = (x > 0 && x < cols - 1) ? isqrt_floor((gx * gx + gy * gy) / 4) : 0;  // <= 180
+                out[k] = (x > 0 && x < cols - 1) ? isqrt_floor_u16((gx * gx + gy * gy) / 4) : 0;  // <= 180
             }
         }
         uint32_t w4[4];
@@ -198,7 +224,46 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, c
         for (int q = 0; q < 4; ++q)
             w4[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) | ((uint32_t)out[4 * q + 3] << 24);
         *reinterpret_cast<uint4*>(gm + o) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-        *reinterpret_cast<uint4*>(pk + o) = make_uint4(0u, 0u, 0u, 0u);
+        if (clear) *reinterpret_cast<uint4*>(pk + o) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if constexpr (MAXIMA) {  // The first selection round's block maxima (dso.rs:192-222 at the initial block size 4; dso_rounds_kernel then skips its pass over the
+        // gmag plane in round 0): a 4 x 4 block = 4 pixels of each of 4 threads (rows: lanes 8 and 16 apart, exchanged through the swizzle
+        // crossbar). First maximum in column-major order = the largest key (value << 4 | 15 - (4 j + i)). The thread of a block's first row
+        // stores its four blocks at once (4 bytes + 16 bytes) where the pair's planes are aligned for that.
+        const int i = (lane >> 3) & 3;
+        int key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = -1;
+            if (own) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k = max(k, (out[4 * q + j] << 4) | (15 - (4 * j + i)));
+            }
+            k = max(k, __builtin_amdgcn_ds_swizzle(k, 0x201f));  // lane ^ 8
+            k = max(k, __builtin_amdgcn_ds_swizzle(k, 0x401f));  // lane ^ 16
+            key[q] = k;
+        }
+        if (own && i == 0) {
+            uint8_t* max_g = ws.max_g + (size_t)pair * ws.max_stride;
+            uint32_t* max_pos = ws.max_pos + (size_t)pair * ws.max_stride;
+            const int t = (y >> 2) * (cols >> 2) + (x0 >> 2);
+            uint32_t pos[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = 15 - (key[q] & 15);
+                pos[q] = (uint32_t)((y + (idx & 3)) * cols + x0 + 4 * q + (idx >> 2));
+            }
+            if ((reinterpret_cast<uintptr_t>(max_g + t) & 3) == 0 && (reinterpret_cast<uintptr_t>(max_pos + t) & 15) == 0) {
+                *reinterpret_cast<uint32_t*>(max_g + t) = (uint32_t)(key[0] >> 4) | ((uint32_t)(key[1] >> 4) << 8) | ((uint32_t)(key[2] >> 4) << 16) | ((uint32_t)(key[3] >> 4) << 24);
+                *reinterpret_cast<uint4*>(max_pos + t) = make_uint4(pos[0], pos[1], pos[2], pos[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    max_g[t + q] = (uint8_t)(key[q] >> 4);
+                    max_pos[t + q] = pos[q];
+                }
+            }
+        }
     }
     __syncthreads();
     if (own) {  // the thread's 16 values into its region's histogram, run by run
@@ -245,7 +310,7 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, c
 // All rounds of one pair in one workgroup (dso.rs:98-147): region thresholds, then up to three rounds of
 //   block maxima at the current base size -> two halvings -> picking at the three levels -> decision,
 // with workgroup barriers between the phases (the planes live in global memory; a barrier orders them within the workgroup).
-// Picks are stamped with (round << 2 | level + 1) so that later rounds need not clear the plane.
+// Picks are stamped with (epoch << 4 | round << 2 | level + 1) so that neither later rounds nor later keyframes need to clear the plane.
 template <typename F>
 __device__ __forceinline__ void dso_for_each(int n, F f) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) f(t);
@@ -262,7 +327,7 @@ struct DsoListOut {
     int count_stride, cap_n;
 };
 __device__ __forceinline__ uint32_t morton_part(uint32_t v);
-__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoListOut out) {
+__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoListOut out, int have_first_maxima) {
     __shared__ DsoState st;
     __shared__ int s_count, s_list_n, s_out_n;
     const int pair = select_pair(g, blockIdx.x);
@@ -296,6 +361,7 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
         st.random_keep = -1;
         st.count = 0;
         st.final_round = 0;
+        st.epoch = dso_next_epoch(ws.state[pair].epoch);
     }
     __syncthreads();
     for (int round = 0; round < 3; ++round) {  // first call + at most nb_iterations_left = 2 recursive calls
@@ -321,7 +387,8 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
         // level-0 block maxima (dso.rs:192-222): first maximum in column-major order; masks of the next levels all true (dso.rs:259)
         dso_for_each(moff[DSO_LEVELS + 1], [&](int t) { mask1[t] = 1; });
         const bool dword_blocks = bs == 4 && cols % 4 == 0 && reinterpret_cast<uintptr_t>(gm) % 4 == 0;
-        dso_for_each(r[0] * c[0], [&](int t) {
+        // (round 0 after the strip kernel: that kernel left the 4 x 4 block maxima here already)
+        if (!(round == 0 && have_first_maxima)) dso_for_each(r[0] * c[0], [&](int t) {
             const int bi = t / c[0], bj = t - bi * c[0];
             const int si = bi * bs, sj = bj * bs, ei = min(si + bs, rows), ej = min(sj + bs, cols);
             if (dword_blocks && ei - si == 4) {  // the first round's 4x4 blocks: four dword loads instead of sixteen byte loads
@@ -392,7 +459,7 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
                     const float threshold = (float)thresh[(ig / DSO_REGION) * rc + jg / DSO_REGION];
                     if ((float)mg >= coef * threshold) {
                         mask_next[(i / 2) * nw + j / 2] = 0;
-                        picked[pos] = (uint8_t)((round << 2) | (l + 1));
+                        picked[pos] = (uint8_t)((st.epoch << 4) | (round << 2) | (l + 1));
                         ++local;
                         if (out.gsort) {
                             const int idx = atomicAdd(&s_list_n, 1);
@@ -463,7 +530,7 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
     if (threadIdx.x == 0) out.count[(size_t)pair * out.count_stride] = s_out_n;  // (> cap_n: band mode, like the scan kernel's overflow)
 }
 __device__ __forceinline__ uint8_t dso_final_mask(const DsoState& st, int stamp, int t, int cols) {
-    bool m = (stamp & 3) != 0 && (stamp >> 2) == st.final_round;
+    bool m = (stamp & 3) != 0 && ((stamp >> 2) & 3) == st.final_round && (stamp >> 4) == st.epoch;
     if (m && st.random_keep >= 0) {  // random sub-sampling branch (dso.rs:140-143), counter-hash instead of thread_rng
         const int i = t / cols, j = t - i * cols;
         const uint8_t r = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)i << 32) | (uint32_t)j)) & 0xff);
@@ -478,7 +545,7 @@ __device__ __forceinline__ uint32_t dso_final_bits16(const DsoState& st, const u
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int stamp = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
-        if ((stamp & 3) != 0 && (stamp >> 2) == st.final_round) cand |= 1u << k;
+        if ((stamp & 3) != 0 && ((stamp >> 2) & 3) == st.final_round && (stamp >> 4) == st.epoch) cand |= 1u << k;
     }
     if (st.random_keep >= 0) {
         uint32_t keep = 0;
@@ -519,9 +586,15 @@ __global__ __launch_bounds__(256) void dso_finalize_kernel(Geom g, DsoWs ws, uin
 // Selection up to the pick stamps (gradient magnitude + region medians, then all rounds of one pair in one workgroup).
 static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pairs, hipStream_t s, DsoListOut out = DsoListOut{}) {
     const bool wide_img = g.lv[0].cols % 4 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 4 == 0;
+    int have_first_maxima = 0;
     if (g.lv[0].cols % 16 == 0 && g.S0 % 16 == 0 && reinterpret_cast<uintptr_t>(kf.level0) % 16 == 0) {
         const int rr = (g.lv[0].rows + DSO_REGION - 1) / DSO_REGION, strips = (g.lv[0].cols + 127) / 128;
-        hipLaunchKernelGGL(dso_gradmag_median_strip_kernel, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+        // the strip kernel also leaves round 0's block maxima (4096 pairs: +0.155 ms there, -0.205 ms in the rounds kernel);
+        // VORS_DSO_FIRST_MAXIMA=0: the rounds kernel computes them from the gmag plane (A/B and tests)
+        const char* fm = getenv("VORS_DSO_FIRST_MAXIMA");
+        have_first_maxima = (fm && atoi(fm) == 0) ? 0 : 1;
+        if (have_first_maxima) hipLaunchKernelGGL(dso_gradmag_median_strip_kernel<true>, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+        else hipLaunchKernelGGL(dso_gradmag_median_strip_kernel<false>, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
     } else {
         hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
     }
@@ -534,7 +607,7 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
     // — twelve wavefronts, three per SIMD, two workgroups per CU — are fastest from 512 pairs on (4096 pairs: step 5.00 ms with 512 threads,
     // 5.06 with 1024, 4.84 with 768), 1024 for the small batches (the shortest chain per pair).
     const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 512 ? 768 : 1024);
-    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out);
+    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out, have_first_maxima);
 }
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
@@ -1337,11 +1410,13 @@ void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs
     // ones go through in several groups of bands); VORS_DSO_PLANES=1 forces the plane path.
     int cap_n = 1;
     while (2 * cap_n <= pp.stride / 3) cap_n *= 2;
-    static const bool force_planes = getenv("VORS_DSO_PLANES") && atoi(getenv("VORS_DSO_PLANES")) != 0;
+    const char* env_planes = getenv("VORS_DSO_PLANES");  // (read per launch: tests switch forms on one handle)
+    const bool force_planes = env_planes && atoi(env_planes) != 0;
     if (!force_planes && cap_n >= (1 << (g.L - 1)) * g.lv[0].cols && g.lv[0].cols < 65536 && g.lv[0].rows < 65536) {  // a band alone fits
         // (from the pick stamps: nobody reads the final mask plane in this form, so it is not written)
         uint8_t* no_mask = nullptr;
-        static const bool use_scan = getenv("VORS_DSO_SCAN") && atoi(getenv("VORS_DSO_SCAN")) != 0;
+        const char* env_scan = getenv("VORS_DSO_SCAN");
+        const bool use_scan = env_scan && atoi(env_scan) != 0;
         if (use_scan) {  // the usable picks extracted by a pass over the stamp plane (round 2's form; same lists after the sort)
             launch_dso_selection(g, kf, ws, n_pairs, s);
             launch_zero_ints(g, pp.counts, pp.chunks_total, n_pairs, s);

@@ -122,6 +122,7 @@ struct Records {
 // Workspace of the DSO-style selector (dso_kernels.hip), all per pair.
 struct DsoState {
     int base_size, iterations_left, done, random_keep, count, final_round;
+    int epoch;  // 1 .. 15: the selection this pair's pick stamps belong to (dso_kernels.hip: the stamp plane is cleared when it wraps, not per keyframe)
 };
 struct DsoWs {
     uint8_t* gmag;      // [S0] gradient magnitude (<= 180)
@@ -213,6 +214,7 @@ void launch_pyramid(const Geom& g, Pyramid pyr, int n_pairs, hipStream_t s);
 void launch_zero_ints(const Geom& g, int* base, int stride, int n_pairs, hipStream_t s);  // per-pair counters -> 0 (honours Geom::sel_list)
 void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records rec, int n_pairs, hipStream_t s);
 void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions);  // coarse-to-fine mode: roots per wavefront region, regions per pair
+int count_isqrt_u16_mismatches(hipStream_t s);  // dso_kernels.hip: self-check of the gradient-magnitude root (0 = exact for every argument)
 void launch_keyframe_dso(const Geom& g, Pyramid kf, const uint16_t* depth, DsoWs ws, uint8_t* mask, PixelPlanes pp, Records rec, int n_pairs,
                          hipStream_t s);
 // Inspection: expand the slim records of one level of one pair into record planes (exact arithmetic).

@@ -270,11 +270,31 @@ __device__ __forceinline__ RefTap2 refw_warp2(const V3G<F2>& P, bool va, bool vb
     const unsigned pitch = (unsigned)(TR ? c.rows : c.cols);
     const unsigned offa = t.ina ? (TR ? (unsigned)((int)uf.a * c.rows + (int)vf.a) : (unsigned)((int)vf.a * c.cols + (int)uf.a)) : 0u;
     const unsigned offb = t.inb ? (TR ? (unsigned)((int)uf.b * c.rows + (int)vf.b) : (unsigned)((int)vf.b * c.cols + (int)uf.b)) : 0u;
+#ifdef VORS_REFW_FAKE_TAPS  // (experiment: every tap from the first 4 KB of the image = the cache-resident bound of the stage)
+    const unsigned offa_ = offa & 0xfffu, offb_ = offb & 0xfffu;
+#define offa offa_
+#define offb offb_
+#endif
     uint16_t a0, a1, b0, b1;
     __builtin_memcpy(&a0, c.img + offa, 2);
     __builtin_memcpy(&b0, c.img + offb, 2);
     __builtin_memcpy(&a1, c.img + (offa + pitch), 2);
     __builtin_memcpy(&b1, c.img + (offb + pitch), 2);
+#ifdef VORS_REFW_FAKE_TAPS
+#undef offa
+#undef offb
+#endif
+#if defined(VORS_REFW_DOUBLE) && (VORS_REFW_DOUBLE & 16)  // ablation: every tap gather issued twice (the second one 64 bytes on: other lines)
+    {
+        uint16_t a2, a3, b2, b3;
+        const unsigned far = t.ina ? 64u : 0u, fbr = t.inb ? 64u : 0u;
+        __builtin_memcpy(&a2, c.img + (offa + far), 2);
+        __builtin_memcpy(&b2, c.img + (offb + fbr), 2);
+        __builtin_memcpy(&a3, c.img + (offa + pitch + far), 2);
+        __builtin_memcpy(&b3, c.img + (offb + pitch + fbr), 2);
+        if ((unsigned)(a2 + a3 + b2 + b3) == 123457u) a0 += 1;
+    }
+#endif
     t.t0a = a0; t.t1a = a1; t.t0b = b0; t.t1b = b1;
     t.fa = u - uf;
     t.fb = v - vf;
@@ -455,10 +475,24 @@ __device__ unsigned long long refc_prof[10];  // workgroup kernel: producer 0 wa
 __device__ unsigned long long refw_prof[8];  // 0 eval cycles (coop: wavefront 0 summing), 1 step cycles, 2 groups of 64 points (coop: barriers), 3 evaluations,
                                              // 4 kernel cycles, 5 wavefronts, 6 coop: verdict + step + publish, 7 coop: wavefront 0 at barriers
 #define REFW_T0(v) const unsigned long long v = __builtin_readcyclecounter()
-#define REFW_ADD(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&refw_prof[slot], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long refw_lvl_prof[8][3];  // per level (by the power of two of its width): evaluation cycles, groups of 64, evaluations
+// (accumulated per wavefront in LDS and flushed once: per-call atomics of 4096 wavefronts in lockstep distort what they measure)
+__device__ __forceinline__ unsigned long long* refw_lacc() {
+    __shared__ unsigned long long a[8][32];
+    return a[threadIdx.x >> 6];
+}
+#define REFW_ADD(slot, v) do { if ((threadIdx.x & 63) == 0) refw_lacc()[slot] += (unsigned long long)(v); } while (0)
+#define REFW_LVL(cols, cyc, groups) do { if ((threadIdx.x & 63) == 0) { unsigned long long* a_ = refw_lacc() + 8 + 3 * min(7, max(0, 27 - __clz(cols))); \
+    a_[0] += (unsigned long long)(cyc); a_[1] += (unsigned long long)(groups); a_[2] += 1ull; } } while (0)
+#define REFW_INIT() do { if ((threadIdx.x & 63) < 32) refw_lacc()[threadIdx.x & 63] = 0ull; } while (0)
+#define REFW_FLUSH() do { const int l_ = threadIdx.x & 63; if (l_ < 32) { const unsigned long long v_ = refw_lacc()[l_]; \
+    if (v_) atomicAdd(l_ < 8 ? &refw_prof[l_] : &refw_lvl_prof[(l_ - 8) / 3][(l_ - 8) % 3], v_); } } while (0)
 #else
 #define REFW_T0(v)
 #define REFW_ADD(slot, v)
+#define REFW_LVL(cols, cyc, groups)
+#define REFW_INIT()
+#define REFW_FLUSH()
 #endif
 
 // One evaluation — eval_energy + compute_eval_data (lm_optimizer.rs:68-107) — of the n points of `src` at `model` by ONE wavefront,
@@ -611,6 +645,7 @@ __device__ __forceinline__ float refw_eval2(const Src& src, int n, const RefImg&
     REFW_ADD(0, __builtin_readcyclecounter() - t_begin);
     REFW_ADD(2, (n + 63) >> 6);
     REFW_ADD(3, 1);
+    REFW_LVL(c.cols, __builtin_readcyclecounter() - t_begin, (n + 63) >> 6);
     return acc;
 }
 
@@ -915,6 +950,7 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
     const int pair = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (pair >= n_pairs) return;
     float* lds = lds_all + wave * RW_WORDS;
+    REFW_INIT();
     REFW_T0(t_kernel);
     const Iso prev_pose = prev_poses7 ? iso_load(prev_poses7 + 7 * pair) : iso_identity();
     const Iso kf_pose = kf_poses7 ? iso_load(kf_poses7 + 7 * pair) : iso_identity();
@@ -950,6 +986,10 @@ __global__ __launch_bounds__(64 * RW_WPB, 4) void lm_ref_track_kernel(Geom g, co
     }
     REFW_ADD(4, __builtin_readcyclecounter() - t_kernel);
     REFW_ADD(5, 1);
+#ifdef VORS_REFW_TIMING
+    if (lane == 0) atomicMax(&refw_prof[7], (unsigned long long)(__builtin_readcyclecounter() - t_kernel));  // (slot 7 here: the longest wavefront)
+#endif
+    REFW_FLUSH();
     if (ho_after > 0 && lane == 0) atomicAdd(&rec.handoff.counters[1], 1);  // one pair fewer to wait for (before the epilogue: the stragglers may go now)
     ref_finish_pair<SRC>(g, pair, kf0, kfu, kf_depth, rec, lm_model, went_well, prev_pose, kf_pose, lds, out_poses7, out_status, out_stats);
 }
@@ -1090,6 +1130,7 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
     const RefResume* saved = resume ? rec.handoff.state + pair : nullptr;
     const int first_lvl = resume ? __builtin_amdgcn_readfirstlane(saved->lvl) : g.L - 1;
     REFW_T0(t_kernel);
+    REFW_INIT();
     if (threadIdx.x == 0) {
         sh.cnt[0] = 0;
         sh.cnt[1] = 0;
@@ -1156,6 +1197,7 @@ __global__ __launch_bounds__(512) void lm_ref_track_coop_kernel(Geom g, const ui
         atomicAdd(&refc_prof[8], (unsigned long long)(__builtin_readcyclecounter() - t_kernel));
         atomicAdd(&refc_prof[9], 1ull);
     }
+    REFW_FLUSH();
 #endif
     (void)prof;
     if (wave != 0) return;  // (no barrier below)
@@ -1288,6 +1330,14 @@ extern "C" int vors_debug_refc_profile(unsigned long long out[10], int reset) { 
     if (reset) {
         unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(vors::refc_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" int vors_debug_refw_level_profile(unsigned long long out[24], int reset) {  // development build only
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vors::refw_lvl_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[24] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vors::refw_lvl_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
 }

@@ -91,7 +91,7 @@ class vors_obs(C.Structure):
 
 # every symbol include/vors_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    "vors_last_error", "vors_device_count", "vors_device_info", "vors_abi_version",
+    "vors_last_error", "vors_device_count", "vors_device_info", "vors_abi_version", "vors_selfcheck_isqrt",
     "vors_tracker_create", "vors_tracker_track", "vors_tracker_track_checked", "vors_tracker_current_frame", "vors_tracker_last_stats",
     "vors_tracker_keyframe", "vors_tracker_destroy",
     "vors_track_pairs",
@@ -211,6 +211,14 @@ def device_info(device=0):
     lib().vors_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     _check(lib().vors_device_info(int(device), C.byref(clk), C.byref(cu), C.byref(mem)))
     return dict(clock_khz=clk.value, compute_units=cu.value, memory_bytes=mem.value)
+
+
+def selfcheck_isqrt():
+    """Arguments 0 .. 65535 for which the DSO selector's four-instruction integer root differs from floor(sqrt(n)) on this device (0)."""
+    n = C.c_int(-1)
+    lib().vors_selfcheck_isqrt.argtypes = [C.POINTER(C.c_int)]
+    _check(lib().vors_selfcheck_isqrt(C.byref(n)))
+    return n.value
 
 
 def _ptr(a):
