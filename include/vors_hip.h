@@ -111,7 +111,8 @@ int vors_abi_version(void);  /* 2: vors_config.arithmetic, vors_pair_stats.nb_gr
                               * 3: vors_trackers_*, vors_synth_render_frames, vors_multi_rccl_version, vors_pipeline_*, vors_device_info,
                               *    vors_tracker_track_checked
                               * 4: VORS_ARITH_REFERENCE, vors_obs.arithmetic, vors_ref_sincos
-                              * 5: VORS_ARITH_* renumbered: 0 = REFERENCE (a zero-initialised vors_config reproduces the reference), 1 = EXACT, 2 = FUSED */
+                              * 5: VORS_ARITH_* renumbered: 0 = REFERENCE (a zero-initialised vors_config reproduces the reference), 1 = EXACT, 2 = FUSED
+                              *    (+ vors_selfcheck_isqrt, added without a signature change) */
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Tracker: one sequence, host buffers.  Replaces
