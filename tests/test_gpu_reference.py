@@ -301,7 +301,8 @@ def test_every_kernel_form_gives_the_oracles_bits(monkeypatch, mode):
         kg, kd, cg, cd, gt = synth(n, rows, cols, intr, 0x5EED9100 + mode, blocky=(mode == 2))
         ref = O.track_pairs(O.make_config(L, intr, candidates_mode=mode, huber_delta=huber), kg, kd, cg)
         forms = {"one wavefront per pair": {"VORS_REF_COOP": "0"},
-                 "workgroup of 2": {"VORS_REF_COOP": "2"}, "workgroup of 5": {"VORS_REF_COOP": "5"}, "workgroup of 8": {"VORS_REF_COOP": "8"},
+                 "workgroup of 2": {"VORS_REF_COOP": "2"}, "workgroup of 3": {"VORS_REF_COOP": "3"}, "workgroup of 4": {"VORS_REF_COOP": "4"},
+                 "workgroup of 5": {"VORS_REF_COOP": "5"}, "workgroup of 8": {"VORS_REF_COOP": "8"},
                  "hand-over after 25 % to workgroups of 4": {"VORS_REF_COOP": "0", "VORS_REF_HANDOFF_MIN_PAIRS": "1", "VORS_REF_HANDOFF": "25"},
                  "hand-over after 1 pair to workgroups of 2": {"VORS_REF_COOP": "0", "VORS_REF_HANDOFF_MIN_PAIRS": "1", "VORS_REF_HANDOFF": "5",
                                                                "VORS_REF_HANDOFF_WAVES": "2"}}

@@ -1217,8 +1217,28 @@ static int refw_waves_per_block(int n_pairs) {
 // Wavefronts per PAIR: a batch that cannot fill the chip with one wavefront per pair gets a workgroup per pair (2 .. 8 wavefronts: one owns
 // the chains, the others produce; LDS 2 x P x 7.6 KB). VORS_REF_COOP overrides (0 = one wavefront per pair, 2 .. 8). Measured at 512
 // pairs (3 / 4 / 5 / 6 wavefronts): coarse-to-fine 0.62 / 0.53 / 0.50 / 0.51 ms, DSO 1.08 / 0.86 / 0.81 / 0.84, dense 14.7 / 10.3 / 9.3 / 9.8.
-static int refc_waves_per_pair(int n_pairs) {
-    int w = n_pairs <= 320 ? 8 : (n_pairs <= 1280 ? 5 : 0);
+// Wavefronts per pair of the workgroup kernel: the LARGEST workgroup of {8, 5, 4, 3} wavefronts of which the whole batch is resident at once
+// (per CU: 16 wavefronts, 160 KB of LDS at 2 (W - 1) blocks of 7.6 KB per workgroup — MI355X: 256 pairs with 8, 512 with 5, 768 with 4,
+// 1280 with 3); a batch that needs a second round of workgroups is slower than a thinner workgroup for everyone (tools/coop_sweep.py: 320
+// pairs 0.83 ms per step with 8 wavefronts, 0.65 with 5; 1024 pairs 1.52 with 5, 1.22 with 3). Beyond that: one wavefront per pair.
+static int refc_waves_per_pair(int n_pairs, bool dense) {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    int w = 0;
+    for (int cand : {8, 5, 4, 3}) {
+        const size_t lds = (size_t)2 * (cand - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
+        const long long per_cu = std::min<long long>(16 / cand, (long long)((size_t)160 * 1024 / lds));
+        if (per_cu * cus >= n_pairs) {
+            w = cand;
+            break;
+        }
+    }
+    // dense: two producers do not keep up with the chains of 409,600 points (1024 pairs: 20.5 ms per step with 3 wavefronts, 18.9 with 5 in
+    // two rounds of workgroups) — five up to 1280 pairs as before
+    if (dense && w < 4 && n_pairs <= 5 * cus) w = 5;
     if (const char* e = getenv("VORS_REF_COOP")) {
         const int v = atoi(e);
         if (v == 0 || (v >= 2 && v <= 8)) w = v;
@@ -1232,7 +1252,7 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
     const bool huber = g.huber_delta > 0.f;
     // dense mode: the column-major planes (capi.cpp allocates and fills them for every REFERENCE handle); without them, the gathering source
     const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.recs ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
-    const int coop = refc_waves_per_pair(n_pairs);
+    const int coop = refc_waves_per_pair(n_pairs, g.mode == VORS_CANDIDATES_DENSE);
 #define VORS_REF_DISPATCH(KERNEL)                                                                              \
     do {                                                                                                       \
         if (src == REF_SRC_DENSE_T) {                                                                          \
