@@ -36,9 +36,12 @@ np.savez(out, **res)
 """
 
 
-def run(tmp_path, tag, planes, rows, cols, L, scan=False, threads=None, sort=None):
+def run(tmp_path, tag, planes, rows, cols, L, scan=False, threads=None, sort=None, extra_env=None):
     out = str(tmp_path / f"{tag}.npz")
     env = dict(os.environ)
+    for k in ("VORS_DSO_ROUNDS_LDS", "VORS_DSO_STAMPS", "VORS_DSO_FIRST_MAXIMA"):
+        env.pop(k, None)
+    env.update(extra_env or {})
     env["VORS_DSO_PLANES"] = "1" if planes else "0"
     env["VORS_DSO_SCAN"] = "1" if scan else "0"
     env.pop("VORS_DSO_SORT", None)
@@ -97,3 +100,18 @@ def test_bucket_sort_of_the_pick_list_equals_the_bitonic_network(tmp_path, rows,
     b = run(tmp_path, "bitonic", False, rows, cols, L, threads=threads, sort="bitonic")
     for key in a.files:
         assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), key
+
+
+@pytest.mark.parametrize("rows,cols,L", [(480, 640, 6), (96, 128, 3), (64, 96, 2), (960, 1280, 7)])
+def test_selection_round_forms_give_the_same_lists(tmp_path, rows, cols, L):
+    """Round 5: the first selection round runs on the first pass's 4 x 4 block maxima with the two upper block levels in LDS, and in the list
+    form it writes its pick stamps only when something will read them (a pick list or a sort buffer that overflows: 64 x 96 goes through
+    in groups of bands, from the stamps). Against the stamps always written (VORS_DSO_STAMPS=1), the generic rounds on the planes in global
+    memory (VORS_DSO_ROUNDS_LDS=0; 1280 x 960 takes them anyway: its upper levels do not fit) and the block maxima recomputed by the rounds
+    kernel (VORS_DSO_FIRST_MAXIMA=0): identical lists, values and poses, bit for bit."""
+    a = run(tmp_path, "default", False, rows, cols, L)
+    for tag, env in (("stamps", {"VORS_DSO_STAMPS": "1"}), ("global", {"VORS_DSO_ROUNDS_LDS": "0"}), ("nomax", {"VORS_DSO_FIRST_MAXIMA": "0"})):
+        b = run(tmp_path, tag, False, rows, cols, L, extra_env=env)
+        for key in a.files:
+            assert a[key].shape == b[key].shape and (a[key].view(np.uint8) == b[key].view(np.uint8)).all(), (tag, key)
+

@@ -315,6 +315,27 @@ template <typename F>
 __device__ __forceinline__ void dso_for_each(int n, F f) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) f(t);
 }
+// The same with DSO_BATCH items per thread and trip in two steps — every item's loads are issued before the first item's stores: the phases
+// of the rounds kernel are chains of dependent global round trips (25 trips of 2 at the finest level with one item at a time: 50 of the
+// ~90 us a workgroup lasts), and byte stores in between keep the compiler from overlapping the items itself.
+#define DSO_BATCH 4
+template <typename T, typename L, typename S>
+__device__ __forceinline__ void dso_for_each_batched(int n, L load, S store) {
+    for (int t0 = threadIdx.x; t0 < n; t0 += (int)blockDim.x * DSO_BATCH) {
+        T in[DSO_BATCH];
+#pragma unroll
+        for (int u = 0; u < DSO_BATCH; ++u) {
+            const int t = t0 + u * (int)blockDim.x;
+            if (t < n) in[u] = load(t);
+        }
+#pragma unroll
+        for (int u = 0; u < DSO_BATCH; ++u) {
+            const int t = t0 + u * (int)blockDim.x;
+            if (t < n) store(t, in[u]);
+        }
+    }
+}
+#define DSO_LDS_REGIONS 2048  // region thresholds in LDS up to this many regions (640x480: 300, 1920x1080: 2040)
 // `out` (when out.gsort is set — the sparse keyframe form): the picks of the final round are also kept as a LIST, and the workgroup turns
 // it straight into what mask_sparse_scan_kernel would extract from the stamp plane — the usable picks (final mask && depth != 0) as
 // (Morton code << 16 | depth) words in out.gsort, their number in *out.count — so that the 307 k-pixel plane is never scanned for ~2000
@@ -327,9 +348,10 @@ struct DsoListOut {
     int count_stride, cap_n;
 };
 __device__ __forceinline__ uint32_t morton_part(uint32_t v);
-__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoListOut out, int have_first_maxima) {
+__global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoListOut out, int have_first_maxima, int stamps_always) {
     __shared__ DsoState st;
     __shared__ int s_count, s_list_n, s_out_n;
+    __shared__ uint16_t s_thresh[DSO_LDS_REGIONS];
     const int pair = select_pair(g, blockIdx.x);
     if (pair < 0) return;
     const int rows = g.lv[0].rows, cols = g.lv[0].cols;
@@ -353,7 +375,9 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
             }
         const float tt = (float)sum / (float)n + 3.0f;
         thresh[t] = (uint16_t)(1.0f * tt * tt);
+        if (t < DSO_LDS_REGIONS) s_thresh[t] = (uint16_t)(1.0f * tt * tt);
     });
+    const bool thresh_in_lds = ws.n_regions <= DSO_LDS_REGIONS;
     if (threadIdx.x == 0) {
         st.base_size = 4;
         st.iterations_left = 2;
@@ -384,6 +408,124 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
             s_count = 0;
             s_list_n = 0;
         }
+        // ROUND 0 ON THE FIRST PASS'S BLOCK MAXIMA, UPPER LEVELS IN LDS (have_first_maxima = 2: the host found room for them). The generic
+        // form below walks level after level through planes in global memory, a workgroup barrier and a global round trip or two per step;
+        // here a thread owns a level-1 block: it reads its four level-0 children (8 independent loads), takes the level-0 picks (level 0's
+        // mask is all true), and leaves the level-1 maximum and mask in LDS; the same one level up out of LDS; then the level-2 picks. Same
+        // comparisons, same tie rules, same stamps; only the order of the pick list differs (it is sorted afterwards).
+        const bool fast_round = round == 0 && have_first_maxima == 2;
+        if (fast_round) {
+            const bool stamps_now = !out.gsort || stamps_always;
+            extern __shared__ __attribute__((aligned(16))) uint32_t dso_lds[];
+            const int n1 = r[1] * c[1], n2 = r[2] * c[2];
+            uint32_t* p1 = dso_lds;                                 // [n1] position of the level-1 maximum
+            uint32_t* p2 = p1 + n1;                                 // [n2]
+            uint8_t* g1 = reinterpret_cast<uint8_t*>(p2 + n2);      // [n1] its magnitude
+            uint8_t* m1 = g1 + n1;                                  // [n1] level-1 mask
+            uint8_t* g2 = m1 + n1;                                  // [n2]
+            uint8_t* m2 = g2 + n2;                                  // [n2]
+            __syncthreads();  // (s_count, s_list_n reset above)
+            auto thr_at = [&](uint32_t pos) {
+                const int ig = pos / cols, jg = pos - ig * cols;
+                const int reg = (ig / DSO_REGION) * rc + jg / DSO_REGION;
+                return (float)(thresh_in_lds ? s_thresh[reg] : thresh[reg]);
+            };
+            // (list form: the stamps are the fallback of two overflows that this kernel sees itself — it writes them at its end, then only:
+            // 12 M scattered byte stores per 4096 pairs, 0.1 ms)
+            auto pick = [&](uint32_t pos, int l) {
+                if (stamps_now) picked[pos] = (uint8_t)((st.epoch << 4) | (round << 2) | (l + 1));
+                if (out.gsort) {
+                    const int idx = atomicAdd(&s_list_n, 1);
+                    if (idx < ws.list_cap) ws.pick_list[(size_t)pair * ws.list_cap + idx] = pos;
+                }
+            };
+            int local = 0;
+            {   // level 0 picks + level 1
+                const int pc = c[0], cl = c[1];
+                for (int t0 = threadIdx.x; t0 < n1; t0 += (int)blockDim.x * 2) {
+                    uint8_t gv[2][4];
+                    uint32_t pv[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int t = t0 + u * (int)blockDim.x;
+                        if (t < n1) {
+                            const int i = t / cl, j = t - i * cl;
+                            const int idx[4] = {(2 * i) * pc + 2 * j, (2 * i + 1) * pc + 2 * j, (2 * i) * pc + 2 * j + 1, (2 * i + 1) * pc + 2 * j + 1};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                gv[u][k] = max_g[idx[k]];
+                                pv[u][k] = max_pos[idx[k]];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int t = t0 + u * (int)blockDim.x;
+                        if (t < n1) {
+                            bool any = false;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if ((float)gv[u][k] >= 1.0f * thr_at(pv[u][k])) {
+                                    pick(pv[u][k], 0);
+                                    ++local;
+                                    any = true;
+                                }
+                            int b = 3;  // g_max(g1, g_max(g2, g_max(g3, g4))) with `if a < b {b} else {a}` (dso.rs:225-241)
+#pragma unroll
+                            for (int m = 2; m >= 0; --m)
+                                if (!(gv[u][m] < gv[u][b])) b = m;
+                            g1[t] = b == 0 ? gv[u][0] : (b == 1 ? gv[u][1] : (b == 2 ? gv[u][2] : gv[u][3]));
+                            p1[t] = b == 0 ? pv[u][0] : (b == 1 ? pv[u][1] : (b == 2 ? pv[u][2] : pv[u][3]));
+                            m1[t] = any ? 0 : 1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            {   // level 1 picks + level 2
+                const int pc = c[1], cl = c[2];
+                for (int t = threadIdx.x; t < n2; t += (int)blockDim.x) {
+                    const int i = t / cl, j = t - i * cl;
+                    const int idx[4] = {(2 * i) * pc + 2 * j, (2 * i + 1) * pc + 2 * j, (2 * i) * pc + 2 * j + 1, (2 * i + 1) * pc + 2 * j + 1};
+                    uint8_t gv[4];
+                    bool keep = true;  // the level-2 mask: every child unmasked and none of them picked
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        gv[k] = g1[idx[k]];
+                        if (m1[idx[k]] != 0) {
+                            if ((float)gv[k] >= 0.5f * thr_at(p1[idx[k]])) {
+                                pick(p1[idx[k]], 1);
+                                ++local;
+                                keep = false;
+                            }
+                        } else {
+                            keep = false;
+                        }
+                    }
+                    int b = 3;
+#pragma unroll
+                    for (int m = 2; m >= 0; --m)
+                        if (!(gv[m] < gv[b])) b = m;
+                    g2[t] = gv[b];
+                    p2[t] = p1[idx[b]];
+                    m2[t] = keep ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            {   // level 2 picks (remainder rows / columns are never visited, dso.rs:263)
+                const int mh = r[2], mw = c[2];
+                for (int t = threadIdx.x; t < n2; t += (int)blockDim.x) {
+                    const int i = t / mw, j = t - i * mw;
+                    if (i >= mh / 2 * 2 || j >= mw / 2 * 2) continue;
+                    if (m2[t] != 0 && (float)g2[t] >= 0.25f * thr_at(p2[t])) {
+                        pick(p2[t], 2);
+                        ++local;
+                    }
+                }
+            }
+            if (local) atomicAdd(&s_count, local);
+            __syncthreads();
+        } else {
         // level-0 block maxima (dso.rs:192-222): first maximum in column-major order; masks of the next levels all true (dso.rs:259)
         dso_for_each(moff[DSO_LEVELS + 1], [&](int t) { mask1[t] = 1; });
         const bool dword_blocks = bs == 4 && cols % 4 == 0 && reinterpret_cast<uintptr_t>(gm) % 4 == 0;
@@ -430,15 +572,41 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
             const int pc = c[l - 1];
             const uint8_t* pg = max_g + off[l - 1];
             const uint32_t* pp = max_pos + off[l - 1];
-            dso_for_each(r[l] * c[l], [&](int t) {
-                const int i = t / c[l], j = t - i * c[l];
-                const int idx[4] = {(2 * i) * pc + 2 * j, (2 * i + 1) * pc + 2 * j, (2 * i) * pc + 2 * j + 1, (2 * i + 1) * pc + 2 * j + 1};
-                int best = idx[3];  // g_max(g1, g_max(g2, g_max(g3, g4))) with `if a < b {b} else {a}`
-                for (int m = 2; m >= 0; --m)
-                    if (!(pg[idx[m]] < pg[best])) best = idx[m];
-                max_g[off[l] + t] = pg[best];
-                max_pos[off[l] + t] = pp[best];
-            });
+            struct HalveIn {
+                int best;
+                uint8_t g;
+            };
+            const int cl = c[l], offl = off[l];
+            for (int t0 = threadIdx.x; t0 < r[l] * cl; t0 += (int)blockDim.x * DSO_BATCH) {
+                HalveIn in[DSO_BATCH];
+                uint32_t posv[DSO_BATCH];
+#pragma unroll
+                for (int u = 0; u < DSO_BATCH; ++u) {
+                    const int t = t0 + u * (int)blockDim.x;
+                    if (t < r[l] * cl) {
+                        const int i = t / cl, j = t - i * cl;
+                        const int idx[4] = {(2 * i) * pc + 2 * j, (2 * i + 1) * pc + 2 * j, (2 * i) * pc + 2 * j + 1, (2 * i + 1) * pc + 2 * j + 1};
+                        const uint8_t gv[4] = {pg[idx[0]], pg[idx[1]], pg[idx[2]], pg[idx[3]]};
+                        int b = 3;  // g_max(g1, g_max(g2, g_max(g3, g4))) with `if a < b {b} else {a}`
+#pragma unroll
+                        for (int m = 2; m >= 0; --m)
+                            if (!(gv[m] < gv[b])) b = m;
+                        in[u].best = b == 0 ? idx[0] : (b == 1 ? idx[1] : (b == 2 ? idx[2] : idx[3]));
+                        in[u].g = b == 0 ? gv[0] : (b == 1 ? gv[1] : (b == 2 ? gv[2] : gv[3]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < DSO_BATCH; ++u)
+                    if (t0 + u * (int)blockDim.x < r[l] * cl) posv[u] = pp[in[u].best];
+#pragma unroll
+                for (int u = 0; u < DSO_BATCH; ++u) {
+                    const int t = t0 + u * (int)blockDim.x;
+                    if (t < r[l] * cl) {
+                        max_g[offl + t] = in[u].g;
+                        max_pos[offl + t] = posv[u];
+                    }
+                }
+            }
             __syncthreads();
         }
         // picking, finest level first (dso.rs:248-276)
@@ -448,31 +616,47 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
             const uint8_t* mask_cur = mask1 + (l >= 1 ? moff[l] : 0);
             uint8_t* mask_next = mask1 + moff[l + 1];
             int local = 0;
-            dso_for_each(mh * mw, [&](int t) {
-                const int i = t / mw, j = t - i * mw;
-                if (i >= mh / 2 * 2 || j >= mw / 2 * 2) return;  // remainder rows / columns are never visited (dso.rs:263)
-                const bool m = (l == 0) ? true : (mask_cur[t] != 0);
-                if (m) {
-                    const int mg = max_g[off[l] + t];
-                    const uint32_t pos = max_pos[off[l] + t];
-                    const int ig = pos / cols, jg = pos - ig * cols;
-                    const float threshold = (float)thresh[(ig / DSO_REGION) * rc + jg / DSO_REGION];
-                    if ((float)mg >= coef * threshold) {
-                        mask_next[(i / 2) * nw + j / 2] = 0;
-                        picked[pos] = (uint8_t)((st.epoch << 4) | (round << 2) | (l + 1));
-                        ++local;
-                        if (out.gsort) {
-                            const int idx = atomicAdd(&s_list_n, 1);
-                            if (idx < ws.list_cap) ws.pick_list[(size_t)pair * ws.list_cap + idx] = pos;
+            struct PickIn {
+                int mg;
+                uint32_t pos;
+                int kind;  // 0: a remainder row / column, never visited (dso.rs:263); 1: masked off; 2: a candidate block
+            };
+            const int offl = off[l];
+            dso_for_each_batched<PickIn>(
+                mh * mw,
+                [&](int t) {
+                    const int i = t / mw, j = t - i * mw;
+                    PickIn in;
+                    in.kind = (i >= mh / 2 * 2 || j >= mw / 2 * 2) ? 0 : (((l == 0) ? true : (mask_cur[t] != 0)) ? 2 : 1);
+                    in.mg = max_g[offl + t];
+                    in.pos = max_pos[offl + t];
+                    return in;
+                },
+                [&](int t, const PickIn& in) {
+                    if (in.kind == 0) return;
+                    const int i = t / mw, j = t - i * mw;
+                    if (in.kind == 2) {
+                        const uint32_t pos = in.pos;
+                        const int ig = pos / cols, jg = pos - ig * cols;
+                        const int reg = (ig / DSO_REGION) * rc + jg / DSO_REGION;
+                        const float threshold = (float)(thresh_in_lds ? s_thresh[reg] : thresh[reg]);
+                        if ((float)in.mg >= coef * threshold) {
+                            mask_next[(i / 2) * nw + j / 2] = 0;
+                            picked[pos] = (uint8_t)((st.epoch << 4) | (round << 2) | (l + 1));
+                            ++local;
+                            if (out.gsort) {
+                                const int idx = atomicAdd(&s_list_n, 1);
+                                if (idx < ws.list_cap) ws.pick_list[(size_t)pair * ws.list_cap + idx] = pos;
+                            }
                         }
+                    } else {
+                        mask_next[(i / 2) * nw + j / 2] = 0;
                     }
-                } else {
-                    mask_next[(i / 2) * nw + j / 2] = 0;
-                }
-            });
+                });
             if (local) atomicAdd(&s_count, local);
             coef *= 0.5f;
             __syncthreads();
+        }
         }
         // end of the round (dso.rs:115-146): recurse with an adapted block size, or fix the outcome
         if (threadIdx.x == 0) {
@@ -501,33 +685,83 @@ __global__ __launch_bounds__(1024) void dso_rounds_kernel(Geom g, DsoWs ws, DsoL
     }
     if (threadIdx.x == 0) ws.state[pair] = st;
     if (!out.gsort) return;
+    // The stamps of a final round 0 that ran in the LDS form without them (its level-1 / level-2 maxima and masks are still in LDS): the same
+    // comparisons again, stamps only.
+    const bool stamps_missing = have_first_maxima == 2 && !stamps_always && st.final_round == 0;
+    auto stamp_round0 = [&]() {
+        extern __shared__ __attribute__((aligned(16))) uint32_t dso_lds[];
+        const int r0 = (rows + 3) / 4, c0 = (cols + 3) / 4, r1 = r0 / 2, c1 = c0 / 2, r2 = r1 / 2, c2 = c1 / 2, n1 = r1 * c1, n2 = r2 * c2;
+        (void)r0;
+        const uint32_t* p1 = dso_lds;
+        const uint32_t* p2 = p1 + n1;
+        const uint8_t* g1 = reinterpret_cast<const uint8_t*>(p2 + n2);
+        const uint8_t* m1 = g1 + n1;
+        const uint8_t* g2 = m1 + n1;
+        const uint8_t* m2 = g2 + n2;
+        const bool thresh_lds = ws.n_regions <= DSO_LDS_REGIONS;
+        auto thr_at = [&](uint32_t pos) {
+            const int ig = pos / cols, jg = pos - ig * cols;
+            const int reg = (ig / DSO_REGION) * rc + jg / DSO_REGION;
+            return (float)(thresh_lds ? s_thresh[reg] : thresh[reg]);
+        };
+        const uint8_t tag = (uint8_t)(st.epoch << 4);
+        for (int t = threadIdx.x; t < n1; t += (int)blockDim.x) {
+            const int i = t / c1, j = t - i * c1;
+            const int idx[4] = {(2 * i) * c0 + 2 * j, (2 * i + 1) * c0 + 2 * j, (2 * i) * c0 + 2 * j + 1, (2 * i + 1) * c0 + 2 * j + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pos = max_pos[idx[k]];
+                if ((float)max_g[idx[k]] >= 1.0f * thr_at(pos)) picked[pos] = (uint8_t)(tag | 1);
+            }
+        }
+        for (int t = threadIdx.x; t < n2; t += (int)blockDim.x) {
+            const int i = t / c2, j = t - i * c2;
+            const int idx[4] = {(2 * i) * c1 + 2 * j, (2 * i + 1) * c1 + 2 * j, (2 * i) * c1 + 2 * j + 1, (2 * i + 1) * c1 + 2 * j + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m1[idx[k]] != 0 && (float)g1[idx[k]] >= 0.5f * thr_at(p1[idx[k]])) picked[p1[idx[k]]] = (uint8_t)(tag | 2);
+            if (i < r2 / 2 * 2 && j < c2 / 2 * 2 && m2[t] != 0 && (float)g2[t] >= 0.25f * thr_at(p2[t])) picked[p2[t]] = (uint8_t)(tag | 3);
+        }
+    };
     // the final round's picks -> the usable ones as sort words (any order: mask_sparse_records_kernel sorts them)
     if (threadIdx.x == 0) s_out_n = 0;
     __syncthreads();
     const int n_list = s_list_n;
     if (n_list > ws.list_cap) {  // (uniform) overflow: leave it to the scan of the stamp plane
         if (threadIdx.x == 0) out.count[(size_t)pair * out.count_stride] = out.cap_n + 1;
+        if (stamps_missing) stamp_round0();
         return;
     }
     const uint32_t* list = ws.pick_list + (size_t)pair * ws.list_cap;
     const uint16_t* dp = out.depth + (size_t)pair * g.S0;
     uint64_t* gsort = out.gsort + (size_t)pair * out.gsort_stride;
     const DsoState fin = st;
-    for (int i = threadIdx.x; i < n_list; i += blockDim.x) {
-        const int t = (int)list[i], y = t / cols, x = t - y * cols;
-        bool m = true;
-        if (fin.random_keep >= 0) {  // random sub-sampling branch (dso.rs:140-143), the same counter hash as dso_final_mask
-            const uint8_t rr8 = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)y << 32) | (uint32_t)x)) & 0xff);
-            m = rr8 <= (uint8_t)fin.random_keep;
-        }
-        const uint32_t dz = dp[t];
-        if (m && dz != 0) {
-            const int o = atomicAdd(&s_out_n, 1);
-            if (o < out.cap_n) gsort[o] = ((uint64_t)(morton_part((uint32_t)y) | (morton_part((uint32_t)x) << 1)) << 16) | dz;
+    for (int i0 = threadIdx.x; i0 < n_list; i0 += (int)blockDim.x * DSO_BATCH) {  // (positions, then depths: two round trips per DSO_BATCH picks)
+        int tv[DSO_BATCH];
+        uint32_t dzv[DSO_BATCH];
+#pragma unroll
+        for (int u = 0; u < DSO_BATCH; ++u) tv[u] = (i0 + u * (int)blockDim.x < n_list) ? (int)list[i0 + u * (int)blockDim.x] : -1;
+#pragma unroll
+        for (int u = 0; u < DSO_BATCH; ++u) dzv[u] = tv[u] >= 0 ? dp[tv[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < DSO_BATCH; ++u) {
+            if (tv[u] < 0) continue;
+            const int t = tv[u], y = t / cols, x = t - y * cols;
+            bool m = true;
+            if (fin.random_keep >= 0) {  // random sub-sampling branch (dso.rs:140-143), the same counter hash as dso_final_mask
+                const uint8_t rr8 = (uint8_t)(dso_splitmix64(DSO_SEED ^ dso_splitmix64(((uint64_t)(uint32_t)y << 32) | (uint32_t)x)) & 0xff);
+                m = rr8 <= (uint8_t)fin.random_keep;
+            }
+            const uint32_t dz = dzv[u];
+            if (m && dz != 0) {
+                const int o = atomicAdd(&s_out_n, 1);
+                if (o < out.cap_n) gsort[o] = ((uint64_t)(morton_part((uint32_t)y) | (morton_part((uint32_t)x) << 1)) << 16) | dz;
+            }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) out.count[(size_t)pair * out.count_stride] = s_out_n;  // (> cap_n: band mode, like the scan kernel's overflow)
+    if (stamps_missing && s_out_n > out.cap_n) stamp_round0();  // (uniform: band mode reads the stamps)
 }
 __device__ __forceinline__ uint8_t dso_final_mask(const DsoState& st, int stamp, int t, int cols) {
     bool m = (stamp & 3) != 0 && ((stamp >> 2) & 3) == st.final_round && (stamp >> 4) == st.epoch;
@@ -607,7 +841,20 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
     // — twelve wavefronts, three per SIMD, two workgroups per CU — are fastest from 512 pairs on (4096 pairs: step 5.00 ms with 512 threads,
     // 5.06 with 1024, 4.84 with 768), 1024 for the small batches (the shortest chain per pair).
     const int rounds_threads = (forced >= 64 && forced <= 1024 && forced % 64 == 0) ? forced : (n_pairs >= 512 ? 768 : 1024);
-    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), 0, s, g, ws, out, have_first_maxima);
+    // round 0 with the upper block levels in LDS (10 bytes per level-1 block and per level-2 block of the 4 x 4 grid) where they fit next to a
+    // second workgroup of the CU; VORS_DSO_ROUNDS_LDS=0: the generic form on the planes in global memory (A/B and tests)
+    size_t lds = 0;
+    if (have_first_maxima) {
+        const int r1 = ((g.lv[0].rows + 3) / 4) / 2, c1 = ((g.lv[0].cols + 3) / 4) / 2, r2 = r1 / 2, c2 = c1 / 2;
+        const size_t need = ((size_t)r1 * c1 + (size_t)r2 * c2) * 6 + 16;
+        const char* el = getenv("VORS_DSO_ROUNDS_LDS");
+        if (r2 > 0 && c2 > 0 && need <= 56 * 1024 && !(el && atoi(el) == 0)) {
+            lds = need;
+            have_first_maxima = 2;
+        }
+    }
+    const char* es = getenv("VORS_DSO_STAMPS");  // 1: the LDS form writes its pick stamps always (A/B and tests), not only when something will read them
+    hipLaunchKernelGGL(dso_rounds_kernel, dim3(n_pairs), dim3(rounds_threads), lds, s, g, ws, out, have_first_maxima, (es && atoi(es) != 0) ? 1 : 0);
 }
 // ------------------------------------------------------------------------------------------------------------
 // Generic-mask keyframe path: level-0 mask -> inverse-depth pyramid (per-pixel planes, like the dense mode) -> per level, the
