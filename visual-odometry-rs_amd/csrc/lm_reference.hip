@@ -1659,17 +1659,19 @@ void launch_lm_solve_obs_reference(Intr k, int rows, int cols, const uint8_t* im
 // candidate per pixel), so the rank of a candidate is the number of set bits below its key in a bitmap of the level: segments of 2^18
 // keys in LDS, per-thread word totals + a block scan. One workgroup per (level, pair); out of place into `tmp`, then copied back.
 // ------------------------------------------------------------------------------------------------------------
-#define SORT_WORDS 4096  // 131,072 keys per segment: 16 KB of bits + 16 KB of word prefixes
+#define SORT_WORDS_MAX 9600  // at most 307,200 keys per segment (bits + 16-bit word prefixes: 57.6 KB of LDS); a launch per level, sized for it
 #define SORT_BLOCK 512
 #define SORT_U 8          // independent loads in flight per thread (a pass is a chain of global round trips otherwise)
-__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void sort_colmajor_kernel(Geom g, Records rec, int reg_cap) {
-    __shared__ uint32_t bits[SORT_WORDS];
-    __shared__ int wpre[SORT_WORDS];  // set bits in the words before this one (within the segment)
+__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void sort_colmajor_kernel(Geom g, Records rec, int reg_cap, int l_first, int seg_words) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];
+    uint32_t* bits = sort_lds;                                            // [seg_words]
+    uint16_t* wpre = reinterpret_cast<uint16_t*>(sort_lds + seg_words);   // [seg_words] set bits in the words before this one (a list has at most 65536 records; a value that wraps belongs to a word with no record behind it)
     __shared__ int wsum[SORT_BLOCK / 64];
     __shared__ int s_base;
     const int pair = select_pair(g, blockIdx.y);
     if (pair < 0) return;
-    const int l = blockIdx.x;
+    const int l = l_first + (int)blockIdx.x;
+    const unsigned SORT_WORDS = (unsigned)seg_words;
     const int rows = g.lv[l].rows, cols = g.lv[l].cols;
     const unsigned nkeys = (unsigned)rows * (unsigned)cols;
     const int n = min(rec.n_used[(size_t)pair * VORS_MAX_LEVELS + l], g.lv[l].n_slots);
@@ -1719,7 +1721,7 @@ __global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(6)))
             for (int w = 0; w < wave; ++w) run += wsum[w];
             const int base = s_base;
             for (int w = w0; w < w1; ++w) {
-                wpre[w] = run;
+                wpre[w] = (uint16_t)run;
                 run += __popc(bits[w]);
             }
             __syncthreads();
@@ -1939,7 +1941,10 @@ void launch_sort_colmajor(const Geom& g, Records rec, int n_pairs, hipStream_t s
     const char* e = getenv("VORS_REF_SORT_REGCAP");
     int reg_cap = SORT_BLOCK * SORT_U;
     if (e) reg_cap = std::max(0, std::min(reg_cap, atoi(e)));
-    hipLaunchKernelGGL(sort_colmajor_kernel, dim3(g.L, n_pairs), dim3(SORT_BLOCK), 0, s, g, rec, reg_cap);
+    for (int l = 0; l < g.L; ++l) {  // (a launch per level: the bitmap of the level in one segment where it fits, and no more LDS than that)
+        const int words = std::min(SORT_WORDS_MAX, (g.lv[l].rows * g.lv[l].cols + 31) / 32);
+        hipLaunchKernelGGL(sort_colmajor_kernel, dim3(1, n_pairs), dim3(SORT_BLOCK), (size_t)words * 6, s, g, rec, reg_cap, l, words);
+    }
 }
 
 }  // namespace vors
