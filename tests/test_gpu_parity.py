@@ -493,8 +493,9 @@ def test_dso_first_round_block_maxima_from_the_first_pass(first_maxima, monkeypa
             assert (mask == (omask & (kd[p] != 0))).all(), f"{cols}x{rows}, pair {p} (rounds {bs})"
 
 
+@pytest.mark.parametrize("shape", [(120, 160, 4), (64, 96, 2)], ids=["120x160", "64x96_groups_of_bands"])
 @pytest.mark.parametrize("form", [{}, {"VORS_DSO_SCAN": "1"}, {"VORS_DSO_PLANES": "1"}], ids=["pick_lists", "stamp_scan", "mask_planes"])
-def test_dso_pick_stamps_stay_valid_over_many_keyframes_of_one_handle(form, monkeypatch):
+def test_dso_pick_stamps_stay_valid_over_many_keyframes_of_one_handle(form, shape, monkeypatch):
     """The pick stamps carry the epoch of their selection (1 .. 15 per pair) and the stamp plane is cleared only when a pair's epoch wraps
     — not per keyframe. 34 different keyframes through ONE handle (two wraps), in every form that reads the stamps (the scan of the stamp
     plane, the mask planes) and in the default one (pick lists): the level-0 candidates are the oracle's mask every time. (Per-pair epochs under
@@ -502,8 +503,8 @@ def test_dso_pick_stamps_stay_valid_over_many_keyframes_of_one_handle(form, monk
     import torch
     for k, v in form.items():
         monkeypatch.setenv(k, v)
-    rows, cols, L, n = 120, 160, 4, 3
-    intr = O.scaled_intrinsics(rows, cols)
+    (rows, cols, L), n = shape, 3  # (64 x 96: the usable picks overflow the sort buffer — the records kernel reads the stamps, which the
+    intr = O.scaled_intrinsics(rows, cols)  # selection rounds then write at their end only)
     b = V.Batch(vcfg(L, intr, 2), n, rows, cols)
     poses = torch.zeros((n, 7), device="cuda"); status = torch.zeros(n, dtype=torch.int32, device="cuda")
     for it in range(34):
