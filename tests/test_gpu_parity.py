@@ -475,13 +475,15 @@ def test_dso_gradient_magnitude_root_is_exact_for_every_argument():
     assert V.selfcheck_isqrt() == 0
 
 
+@pytest.mark.parametrize("strip4", ["0", "1"], ids=["a_row_per_thread", "four_rows_per_thread"])
 @pytest.mark.parametrize("first_maxima", ["0", "1"])
-def test_dso_first_round_block_maxima_from_the_first_pass(first_maxima, monkeypatch):
+def test_dso_first_round_block_maxima_from_the_first_pass(first_maxima, strip4, monkeypatch):
     """VORS_DSO_FIRST_MAXIMA=1: the gradient-magnitude pass also leaves the 4 x 4 block maxima of the first selection round (first maximum
     in column-major order, dso.rs:192-222) and the rounds kernel skips that pass; same masks as the oracle either way (480 x 640 goes
     through the strip kernel; 60 x 80 has partial regions)."""
     monkeypatch.setenv("VORS_DSO_FIRST_MAXIMA", first_maxima)
-    for rows, cols, L, n in ((480, 640, 6, 2), (60, 80, 3, 2), (250, 336, 4, 2)):
+    monkeypatch.setenv("VORS_DSO_STRIP4", strip4)  # (the first pass with a row or with four rows = whole 4 x 4 blocks per thread)
+    for rows, cols, L, n in ((480, 640, 6, 2), (60, 80, 3, 2), (250, 336, 4, 2), (131, 176, 3, 2)):
         intr = O.scaled_intrinsics(rows, cols)
         kg, kd, cg, cd, gt = O.synth_batch(n, rows, cols, seed0=BLOCKY | 0x5EED1300, intr=intr)
         b, poses, status, stats, _ = run_batch(vcfg(L, intr, 2), kg, kd, cg)

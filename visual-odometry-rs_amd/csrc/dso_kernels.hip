@@ -307,6 +307,154 @@ __global__ __launch_bounds__(256) void dso_gradmag_median_strip_kernel(Geom g, c
     }
 }
 
+__device__ __forceinline__ void kf_wave_sync_dso() {  // (LDS operations of one wavefront execute in order; this keeps the compiler from moving them)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// The same with FOUR ROWS per thread (16 x 4 pixels = four whole 4 x 4 blocks): a WAVEFRONT owns a strip (8 lane columns x 8 row groups =
+// 128 x 32 pixels, four regions, its own four histograms), a workgroup four strips. Six row loads per four output rows instead of twelve,
+// the block maxima without any lane exchange, no workgroup barrier, a quarter of the wavefronts.
+template <bool MAXIMA>
+__global__ __launch_bounds__(256) void dso_gradmag_median_strip4_kernel(Geom g, const uint8_t* __restrict__ kf0, DsoWs ws) {
+    __shared__ int s_hist[4][4][256];  // [wavefront][region of its strip][bin]
+    const int pair = select_pair(g, blockIdx.y);
+    if (pair < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+    const int rr = (rows + DSO_REGION - 1) / DSO_REGION, rc = (cols + DSO_REGION - 1) / DSO_REGION, strips = (cols + 127) / 128;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip >= rr * strips) return;  // (no workgroup barrier below)
+    const int ri = strip / strips, sj = strip - ri * strips;
+    int(*hist4)[256] = s_hist[wave];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<int4*>(&hist4[0][0] + 4 * (lane + 64 * q)) = make_int4(0, 0, 0, 0);
+    const uint8_t* img = kf0 + (size_t)pair * g.S0;
+    uint8_t* gm = ws.gmag + (size_t)pair * g.S0;
+    uint8_t* pk = ws.picked + (size_t)pair * g.S0;
+    const bool clear = dso_next_epoch(ws.state[pair].epoch) == 1;
+    const int x0 = sj * 128 + (lane & 7) * 16, y0 = ri * DSO_REGION + 4 * (lane >> 3);
+    const bool xin = x0 < cols;  // (cols % 16 == 0: a thread's 16 pixels of a row are all inside or all outside)
+    int* hist = hist4[(lane & 7) >> 1];
+    // the six image rows y0 - 1 .. y0 + 4 (clamped: a clamped row is only ever the neighbour of a border row, whose values are 0 anyway)
+    uint4 rw[6];
+    int lf[4], rt[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int y = min(max(y0 - 1 + k, 0), rows - 1);
+        rw[k] = xin ? *reinterpret_cast<const uint4*>(img + (size_t)y * cols + x0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = min(y0 + k, rows - 1);
+        const size_t o = (size_t)y * cols + x0;
+        lf[k] = (xin && x0 > 0) ? img[o - 1] : 0;
+        rt[k] = (xin && x0 + 16 < cols) ? img[o + 16] : 0;
+    }
+    int key[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // row y0 + i
+        const int y = y0 + i;
+        const bool own = xin && y < rows;
+        int out[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] = 0;
+        if (own && y > 0 && y < rows - 1) {
+            const uint32_t u[4] = {rw[i].x, rw[i].y, rw[i].z, rw[i].w}, m[4] = {rw[i + 1].x, rw[i + 1].y, rw[i + 1].z, rw[i + 1].w},
+                           d[4] = {rw[i + 2].x, rw[i + 2].y, rw[i + 2].z, rw[i + 2].w};
+            int row[18];
+            row[0] = lf[i];
+            row[17] = rt[i];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) row[k + 1] = (int)((m[k >> 2] >> (8 * (k & 3))) & 0xff);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int gx = row[k + 2] - row[k];
+                const int gy = (int)((d[k >> 2] >> (8 * (k & 3))) & 0xff) - (int)((u[k >> 2] >> (8 * (k & 3))) & 0xff);
+                const int x = x0 + k;
+                out[k] = (x > 0 && x < cols - 1) ? isqrt_floor_u16((gx * gx + gy * gy) / 4) : 0;  // <= 180
+            }
+        }
+        if (own) {
+            const size_t o = (size_t)y * cols + x0;
+            uint32_t w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w4[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) | ((uint32_t)out[4 * q + 3] << 24);
+            *reinterpret_cast<uint4*>(gm + o) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            if (clear) *reinterpret_cast<uint4*>(pk + o) = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (MAXIMA) {  // first maximum in column-major order = the largest key (value << 4 | 15 - (4 j + i))
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) key[q] = max(key[q], (out[4 * q + j] << 4) | (15 - (4 * j + i)));
+            }
+            int cur = out[0], cnt = 1;  // the row's 16 values into the region's histogram, run by run
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                if (out[k] == cur) {
+                    ++cnt;
+                } else {
+                    atomicAdd(&hist[cur], cnt);
+                    cur = out[k];
+                    cnt = 1;
+                }
+            }
+            atomicAdd(&hist[cur], cnt);
+        }
+    }
+    if constexpr (MAXIMA) {
+        if (xin && y0 < rows) {
+            uint8_t* max_g = ws.max_g + (size_t)pair * ws.max_stride;
+            uint32_t* max_pos = ws.max_pos + (size_t)pair * ws.max_stride;
+            const int t = (y0 >> 2) * (cols >> 2) + (x0 >> 2);
+            uint32_t pos[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = 15 - (key[q] & 15);
+                pos[q] = (uint32_t)((y0 + (idx & 3)) * cols + x0 + 4 * q + (idx >> 2));
+            }
+            if ((reinterpret_cast<uintptr_t>(max_g + t) & 3) == 0 && (reinterpret_cast<uintptr_t>(max_pos + t) & 15) == 0) {
+                *reinterpret_cast<uint32_t*>(max_g + t) = (uint32_t)(key[0] >> 4) | ((uint32_t)(key[1] >> 4) << 8) | ((uint32_t)(key[2] >> 4) << 16) | ((uint32_t)(key[3] >> 4) << 24);
+                *reinterpret_cast<uint4*>(max_pos + t) = make_uint4(pos[0], pos[1], pos[2], pos[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    max_g[t + q] = (uint8_t)(key[q] >> 4);
+                    max_pos[t + q] = pos[q];
+                }
+            }
+        }
+    }
+    kf_wave_sync_dso();
+    // the medians of the strip's four regions = first bin whose inclusive prefix count exceeds len / 2
+    const int h = min(DSO_REGION, rows - ri * DSO_REGION);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int rj = sj * 4 + q;
+        if (rj >= rc) break;
+        const int w = min(DSO_REGION, cols - rj * DSO_REGION);
+        const int4 b = *reinterpret_cast<const int4*>(&hist4[q][4 * lane]);
+        const int mine = b.x + b.y + b.z + b.w;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int kmed = (h * w) / 2;
+        if (incl > kmed && incl - mine <= kmed) {
+            int acc = incl - mine, med = 4 * lane;
+            const int bins[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                if (acc <= kmed && acc + bins[qq] > kmed) med = 4 * lane + qq;
+                acc += bins[qq];
+            }
+            ws.median[(size_t)pair * ws.n_regions + ri * rc + rj] = (uint16_t)med;
+        }
+    }
+}
+
 // All rounds of one pair in one workgroup (dso.rs:98-147): region thresholds, then up to three rounds of
 //   block maxima at the current base size -> two halvings -> picking at the three levels -> decision,
 // with workgroup barriers between the phases (the planes live in global memory; a barrier orders them within the workgroup).
@@ -827,7 +975,11 @@ static void launch_dso_selection(const Geom& g, Pyramid kf, DsoWs ws, int n_pair
         // VORS_DSO_FIRST_MAXIMA=0: the rounds kernel computes them from the gmag plane (A/B and tests)
         const char* fm = getenv("VORS_DSO_FIRST_MAXIMA");
         have_first_maxima = (fm && atoi(fm) == 0) ? 0 : 1;
-        if (have_first_maxima) hipLaunchKernelGGL(dso_gradmag_median_strip_kernel<true>, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+        const char* e4 = getenv("VORS_DSO_STRIP4");  // four rows per thread, a wavefront per strip (4096 pairs: 0.88 -> 0.74 ms); 0: a row per thread (A/B and tests)
+        if (!(e4 && atoi(e4) == 0)) {
+            if (have_first_maxima) hipLaunchKernelGGL(dso_gradmag_median_strip4_kernel<true>, dim3((rr * strips + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+            else hipLaunchKernelGGL(dso_gradmag_median_strip4_kernel<false>, dim3((rr * strips + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
+        } else if (have_first_maxima) hipLaunchKernelGGL(dso_gradmag_median_strip_kernel<true>, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
         else hipLaunchKernelGGL(dso_gradmag_median_strip_kernel<false>, dim3(rr * strips, n_pairs), dim3(256), 0, s, g, kf.level0, ws);
     } else {
         hipLaunchKernelGGL(dso_gradmag_median_kernel, dim3((ws.n_regions + 3) / 4, n_pairs), dim3(256), 0, s, g, kf.level0, ws, wide_img);
