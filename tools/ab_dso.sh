@@ -11,7 +11,7 @@ import csv,sys,collections,statistics
 d=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n=r['Kernel_Name']
-    if 'dso_' in n or 'mask_sparse' in n or 'sort_colmajor' in n:
+    if 'dso_' in n or 'mask_sparse' in n or 'sort_colmajor' in n or 'sparse_fill' in n:
         wg=int(r['Grid_Size_X'])*int(r['Grid_Size_Y'])*int(r['Grid_Size_Z'])
         d[(n[:48],wg)].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 big={}
