@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then falls back to the committed profile)")
     p.add_argument("--no-sequences", action="store_true", help="skip the 64-sequence tracker measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other candidate mode, 256-pair batch)")
+    p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (1280x960, 7 levels, Huber 10, 512 pairs)")
     p.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (kernel timing off)")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="process-group backend for N > 1: nccl (= RCCL over xGMI, the measured configuration) or gloo (control-plane test of "
@@ -335,7 +336,7 @@ def multi_gpu_self_check(args, work, packed, gathered, rank, world):
     against its own poses / statuses, and (through one more all-gather of a per-rank checksum) every other block against its owner's —
     and that the collective library answers its version query. Raises on any mismatch: a wrong gather must fail loudly, not time well."""
     import torch.distributed as dist
-    P = args.pairs
+    P = work.n
     local = torch.empty((P, 8), dtype=torch.float32, device=packed.device)
     local[:, :7] = work.poses
     local[:, 7] = work.status
@@ -520,6 +521,37 @@ def reference_parity(V, args, device, seed0, sizes):
     return out
 
 
+def measure_block(V, a, mode, device, seed0, ring, steps, warmup, pmc, limited_by):
+    """One workload (mode x arithmetic x shape of `a`) at a.pairs pairs: throughput, stage times (HIP events on the stream), the LM stage's
+    algorithmic-byte rate against the HBM peak and — pmc — its live counter traffic (three short rocprofv3 passes of the same command)."""
+    w = Workload(V, a, mode, device, seed0)
+    w.batch.enable_kernel_timing(ring)
+    dt = timed_run(w, steps, warmup, 1, None, None)
+    st = V.decode_stats(w.stats)
+    io, lmb, _, ev, _ = byte_model(st, a.levels, a.rows, a.cols, mode == "dense")
+    lm = float(w.batch.kernel_times("lm")[-steps:].mean())
+    kf = float(w.batch.kernel_times("keyframe")[-steps:].mean())
+    py = float((w.batch.kernel_times("pyramid_keyframe")[-steps:] + w.batch.kernel_times("pyramid_current")[-steps:]).mean())
+    lm_bytes = lmb + 32 * a.pairs
+    cnt = live_counters(a, mode) if pmc else {}
+    tr = cnt.get("traffic_bytes")
+    kernel = ("lm_ref_track_kernel (+ lm_ref_track_coop_kernel for small batches and the pairs handed over)" if a.arith == "reference" else
+              ("lm_track_kernel (coarse levels) + lm_split_eval_kernel / lm_split_step_kernel rounds" if mode == "dense" else "lm_track_kernel"))
+    blk = {"value": round(a.pairs * steps / dt, 2), "unit": "frame-pairs/s", "pairs_per_gpu": a.pairs, "ms_per_step": round(dt / steps * 1e3, 4),
+           "stages_ms": {"pyramids": round(py, 5), "keyframe": round(kf, 5), "lm": round(lm, 5)},
+           "lm_evals_per_pair": round(ev, 2), "failed_pairs": int((w.status != 0).sum().item()),
+           "roofline": {"bound": "hbm", "limited_by": limited_by, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "kernel": kernel,
+                        "achieved": round(lm_bytes / (lm * 1e-3) / 1e9, 2), "frac": round(lm_bytes / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        "algorithmic_bytes_per_launch": lm_bytes, "kernel_ms_avg": round(lm, 5),
+                        "traffic": tr, "traffic_source": cnt.get("source"), "traffic_over_algorithmic": (round(tr / lm_bytes, 3) if tr else None),
+                        "memory_side_frac": (round(tr / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr else None),
+                        "valu_instructions_per_launch": cnt.get("sq_insts_valu"),
+                        "io_only_GBps": round(io * steps / dt / 1e9, 2), "io_only_frac": round(io * steps / dt / 1e9 / HBM_PEAK_GBPS, 5),
+                        "whole_job_frac": round((io + lmb) * steps / dt / 1e9 / HBM_PEAK_GBPS, 5)}}
+    return blk, w, dt
+
+
 def reference_block(V, args, device, seed0, ring):
     """The three candidate modes in VORS_ARITH_REFERENCE — the boundary's default arithmetic (vors_config.arithmetic = 0), the one whose
     poses are bit-identical to the oracle's (`parity_reference`) — at the headline batch size: throughput, stage times, the LM stage's
@@ -530,29 +562,8 @@ def reference_block(V, args, device, seed0, ring):
     out = {"arithmetic": "reference (VORS_ARITH_REFERENCE = 0: the reference's per-point arithmetic and summation order)"}
     for mode in ("c2f", "dso", "dense"):
         steps = args.steps if mode != "dense" else max(2, min(args.steps, 5))   # (a dense step is ~70 ms at 4096 pairs)
-        w = Workload(V, a, mode, device, seed0)
-        w.batch.enable_kernel_timing(ring)
-        dt = timed_run(w, steps, min(args.warmup, 2), 1, None, None)
-        st = V.decode_stats(w.stats)
-        io, lmb, _, ev, _ = byte_model(st, a.levels, a.rows, a.cols, mode == "dense")
-        lm = float(w.batch.kernel_times("lm")[-steps:].mean())
-        kf = float(w.batch.kernel_times("keyframe")[-steps:].mean())
-        py = float((w.batch.kernel_times("pyramid_keyframe")[-steps:] + w.batch.kernel_times("pyramid_current")[-steps:]).mean())
-        lm_bytes = lmb + 32 * a.pairs
-        cnt = live_counters(a, mode) if not args.no_pmc else {}   # three short rocprofv3 passes of this mode in the REFERENCE arithmetic
-        tr = cnt.get("traffic_bytes")
-        blk = {"value": round(a.pairs * steps / dt, 2), "unit": "frame-pairs/s", "pairs_per_gpu": a.pairs, "ms_per_step": round(dt / steps * 1e3, 4),
-               "stages_ms": {"pyramids": round(py, 5), "keyframe": round(kf, 5), "lm": round(lm, 5)},
-               "lm_evals_per_pair": round(ev, 2),
-               "roofline": {"bound": "hbm", "limited_by": "valu (dependent f32 chains + the reference's per-point expressions)", "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "kernel": "lm_ref_track_kernel (+ lm_ref_track_coop_kernel for the pairs handed over)",
-                            "achieved": round(lm_bytes / (lm * 1e-3) / 1e9, 2), "frac": round(lm_bytes / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                            "algorithmic_bytes_per_launch": lm_bytes, "kernel_ms_avg": round(lm, 5),
-                            "traffic": tr, "traffic_source": cnt.get("source"), "traffic_over_algorithmic": (round(tr / lm_bytes, 3) if tr else None),
-                            "memory_side_frac": (round(tr / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr else None),
-                            "valu_instructions_per_launch": cnt.get("sq_insts_valu"),
-                            "io_only_GBps": round(io * steps / dt / 1e9, 2), "io_only_frac": round(io * steps / dt / 1e9 / HBM_PEAK_GBPS, 5),
-                            "whole_job_frac": round((io + lmb) * steps / dt / 1e9 / HBM_PEAK_GBPS, 5)}}
+        blk, w, dt = measure_block(V, a, mode, device, seed0, ring, steps, min(args.warmup, 2), not args.no_pmc,
+                                   "valu (dependent f32 chains + the reference's per-point expressions)")
         del w
         if a.pairs != 512:
             a5 = copy.copy(a)
@@ -565,6 +576,90 @@ def reference_block(V, args, device, seed0, ring):
                                 "step_time_ratio_vs_headline_batch": round((dt / steps) / (dt5 / steps), 3)}
             del w5
         out[mode] = blk
+    return out
+
+
+def config5_block(V, args, device, ring):
+    """BASELINE configs[4] ("config 5") on ONE GPU's share: synthetic 1280x960 RGB-D, 7-level pyramid, Huber weighting (delta = 10 grey
+    levels, the oracle-defined extension), dense candidates, 512 pairs (i = 0..511) — in FUSED (what `value` times at 640x480)
+    and in REFERENCE (the default arithmetic): throughput, stage times, the LM stage's roofline with live PMC traffic, and the oracle on one
+    pinned host core on a sample of the same pairs."""
+    import copy
+    a = copy.copy(args)
+    a.rows, a.cols, a.levels, a.huber, a.pairs = 960, 1280, 7, 10.0, 512
+    out = {"workload": "BASELINE configs[4]: synthetic 1280x960 RGB-D, 7-level pyramid, Huber delta 10, dense candidates, 512 pairs on one GPU"}
+    for arith in ("fused", "reference"):
+        a.arith = arith
+        steps = max(2, min(args.steps, 10 if arith == "fused" else 4))
+        blk, w, dt = measure_block(V, a, "dense", device, 0x5EED0000, ring, steps, 1, not args.no_pmc,
+                                   "valu" if arith == "fused" else "valu (dependent f32 chains + the reference's per-point expressions)")
+        if arith == "fused" and args.cpu_pairs != 0:
+            blk["cpu_baseline"] = cpu_baseline(a, w, blk["value"], n_override=8 if args.cpu_pairs < 0 else min(args.cpu_pairs, 8))
+        if arith == "reference" and args.parity_pairs != 0:   # the default arithmetic at this shape: equality of bits on a sample
+            from oracle import oracle as O
+            n = 16
+            kg, kd, cg = host_pairs(w, n)
+            ref = O.track_pairs(O.make_config(a.levels, w.intr, candidates_mode=w.mode_id, huber_delta=a.huber), kg, kd, cg, n_threads=min(os.cpu_count() or 1, n))
+            poses = w.poses[:n].cpu().numpy()
+            blk["parity_sample"] = {"sample_pairs": n, "n_poses_bit_identical": int((poses.view(np.uint32) == ref["poses"].view(np.uint32)).all(axis=1).sum()),
+                                    "status_equal": bool((w.status[:n].cpu().numpy() == ref["status"]).all())}
+        del w
+        out[arith] = blk
+    return out
+
+
+def single_tracker_bench(V, args, device, n_frames=40):
+    """configs[0] / configs[2] as written are ONE sequence: vors_tracker_* (Config::init / Tracker::track / current_frame through the C ABI,
+    HOST buffers in, pose out — upload, pyramid, LM, keyframe test and promotion per call), milliseconds per frame for the three candidate
+    modes in both arithmetics, beside the oracle's Tracker on one pinned host core over the same frames."""
+    from oracle import oracle as O
+    rows, cols, L = args.rows, args.cols, args.levels
+    intr = V.scaled_intrinsics(rows, cols)
+    step = np.array([0.004, -0.002, 0.0015, 0.0008, -0.001, 0.0005])
+    out = {}
+    for mode in ("c2f", "dso", "dense"):
+        blocky = (1 << 63) if mode == "dso" else 0
+        g, d = V.synth_render_frames([blocky | 31337] * n_frames, list(range(n_frames)), [step * k for k in range(n_frames)], rows, cols, intr, device=device)
+        gh, dh = g.cpu().numpy(), d.cpu().numpy().view(np.uint16)
+        mode_id = {"c2f": V.CANDIDATES_COARSE_TO_FINE, "dso": V.CANDIDATES_DSO, "dense": V.CANDIDATES_DENSE}[mode]
+        blk = {}
+        last = {}
+        for arith in ("reference", "fused"):
+            cfg = V.Config(nb_levels=L, intrinsics=V.Intrinsics(intr[:2], intr[2:4], intr[4]), candidates_mode=mode_id, arithmetic=arith_id(V, arith))
+            for rep in range(2):   # the first pass warms up
+                vt = cfg.init(0.0, dh[0], 0.0, gh[0])
+                ts, traj = [], []
+                for k in range(1, n_frames):
+                    t0 = time.perf_counter()
+                    vt.track(float(k), dh[k], float(k), gh[k])
+                    ts.append(time.perf_counter() - t0)
+                    traj.append(vt.current_frame()[1])
+                del vt
+            ts = np.array(ts) * 1e3
+            last[arith] = np.array(traj, np.float32)
+            blk[arith] = {"ms_per_frame_mean": round(float(ts.mean()), 4), "ms_per_frame_median": round(float(np.median(ts)), 4),
+                          "ms_per_frame_p90": round(float(np.quantile(ts, 0.9)), 4)}
+        ocfg = O.make_config(L, intr, candidates_mode=mode_id)
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, {allowed[len(allowed) // 2]})
+        except (AttributeError, OSError):
+            allowed = None
+        try:
+            O.track_sequences(ocfg, gh[:3, None], dh[:3, None], n_threads=1, variant="native")  # warm-up
+            t0 = time.perf_counter()
+            O.track_sequences(ocfg, gh[:, None], dh[:, None], n_threads=1, variant="native")
+            t_cpu = time.perf_counter() - t0
+        finally:
+            if allowed is not None:
+                os.sched_setaffinity(0, set(allowed))
+        ref = O.track_sequences(ocfg, gh[:, None], dh[:, None], n_threads=1)
+        blk["cpu_oracle_tracker_ms_per_frame_1core"] = round(t_cpu / (n_frames - 1) * 1e3, 4)
+        blk["reference_trajectory_bit_identical_to_oracle_tracker"] = bool((last["reference"].view(np.uint32) == ref["poses"][0].view(np.uint32)).all())
+        blk["fused_max_pose_diff_vs_oracle_tracker"] = float(np.abs(last["fused"] - ref["poses"][0]).max())
+        out[mode] = blk
+    out["note"] = (f"{cols}x{rows}, {L} levels, {n_frames - 1} tracked frames of one synthetic sequence; a frame = one vors_tracker_track call with HOST buffers "
+                   "(upload + pyramid + LM + keyframe test + read-back); the oracle figure is its C++ Tracker on one pinned core, kind \"port\"")
     return out
 
 
@@ -605,6 +700,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     import vors_amd as V
 
+    pairs_weak = args.pairs
     if args.scaling == "strong":  # BASELINE configs[3] as written: a fixed batch sharded over the ranks (equal blocks: the gather wants them equal)
         args.pairs = -(-args.total_pairs // world)
     seed0 = 0x5EED0000 + rank * args.pairs
@@ -706,7 +802,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[1]: synthetic 640x480 RGB-D (gray u8 + depth u16), 6-level pyramid, dense candidates"
+            "workload": (f"BASELINE configs[3]: {args.total_pairs} pairs sharded over {world} ranks (synthetic 640x480 RGB-D, 6-level pyramid, {args.candidates} candidates)"
+                         if world > 1 and args.scaling == "strong" and base_shape and args.huber == 0 else
+                         "BASELINE configs[1]: synthetic 640x480 RGB-D (gray u8 + depth u16), 6-level pyramid, dense candidates"
                          if dense and base_shape and args.huber == 0 else
                          ("BASELINE configs[4] shape: synthetic 1280x960 RGB-D, 7-level pyramid, Huber weighting, dense candidates"
                           if dense and (args.rows, args.cols, args.levels) == (960, 1280, 7) and args.huber > 0 else
@@ -735,6 +833,29 @@ def main():
     parity_secondary = None
     if world > 1:
         out["self_check"] = multi_gpu_self_check(args, main_w, packed, gathered, rank, world)
+        # ---- N > 1: BOTH readings of "throughput at N GPUs" in the one line. `weak` = --pairs per GPU whatever N (the
+        # driver's default contract: per-GPU work fixed); `strong` = BASELINE configs[3] AS WRITTEN: the fixed batch of --total-pairs (4096)
+        # sharded over the N ranks, 4096 / N each. `value` is the one --scaling names (default weak); the other one is timed right after
+        # it with the same steps / warm-up / barrier + MAX-over-ranks rule and its own gather self-check.
+        def scaling_block(kind, work, dt_k, check):
+            per = work.n
+            total = args.total_pairs if kind == "strong" else world * per
+            return {"workload": (f"BASELINE configs[3]: {args.total_pairs} pairs sharded over {world} ranks ({per} per GPU)" if kind == "strong" else
+                                 f"{per} pairs per GPU on {world} ranks ({total} pairs per step)"),
+                    "scaling": kind, "value": round(total * args.steps / dt_k, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt_k / args.steps * 1e3, 4),
+                    "pairs_per_gpu": per, "total_pairs": total, "failed_pairs_rank0": int((work.status != 0).sum().item()), "self_check": check}
+        out[args.scaling] = scaling_block(args.scaling, main_w, dt, out["self_check"])
+        other = "strong" if args.scaling == "weak" else "weak"
+        import copy
+        a2 = copy.copy(args)
+        a2.pairs = -(-args.total_pairs // world) if other == "strong" else pairs_weak
+        w2 = Workload(V, a2, args.candidates, device, 0x5EED0000 + rank * a2.pairs)
+        packed2 = torch.zeros((a2.pairs, 8), dtype=torch.float32, device=device)
+        gathered2 = torch.zeros((world * a2.pairs, 8), dtype=torch.float32, device=device)
+        dt_o = timed_run(w2, args.steps, args.warmup, world, packed2, gathered2)
+        out[other] = scaling_block(other, w2, dt_o, multi_gpu_self_check(a2, w2, packed2, gathered2, rank, world))
+        out["config"]["value_is"] = f"`{args.scaling}` (see the `weak` and `strong` blocks; `strong` is BASELINE configs[3] as written)"
+        del w2, packed2, gathered2
     if rank == 0 and world == 1:
         if not args.no_secondary:
             # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload, and BASELINE config 4's per-GPU share on 8 GPUs (512)
@@ -824,6 +945,9 @@ def main():
             out["reference"] = reference_block(V, args, device, seed0, ring)
         if not args.no_sequences and not args.no_secondary:
             out["sequences_64"] = sequences_bench(V, args, device)
+            out["single_tracker"] = single_tracker_bench(V, args, device)
+        if not args.no_secondary and base_shape and args.huber == 0 and not args.no_config5:
+            out["config5"] = config5_block(V, args, device, ring)
         if not args.no_secondary and args.parity_pairs != 0 and args.arith != "reference":
             sizes = parity_sample_sizes(args)
             out["parity_reference"] = reference_parity(V, args, device, seed0, sizes)
@@ -836,6 +960,11 @@ def main():
             if parity_secondary is not None:
                 out["parity_secondary"] = parity_secondary
     if rank == 0:
+        # "bit-identical to the oracle" is NOT "bit-identical to vors" until a document produced by the Rust reference says so
+        from oracle.rust_pin import parity_pinned
+        pinned, detail = parity_pinned()
+        out["parity_pinned"] = pinned
+        out["parity_pinned_detail"] = detail
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

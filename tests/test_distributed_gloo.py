@@ -153,7 +153,7 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--pairs", "64", "--candidates", "c2f", "--backend", "gloo"]
+           "--pairs", "64", "--total-pairs", "96", "--candidates", "c2f", "--backend", "gloo"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -162,6 +162,16 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["pairs_per_gpu"] == 64 and d["failed_pairs"] == 0
     assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # whole-job aggregate over both ranks
+    # round 6: with N > 1 the one line carries BOTH readings — `weak` (what `value` is by default) and `strong` = BASELINE configs[3] as
+    # written (the fixed batch of --total-pairs sharded over the ranks) — each with its own gather self-check
+    assert "weak" in d["config"]["value_is"]
+    wk, sg = d["weak"], d["strong"]
+    assert wk["scaling"] == "weak" and wk["pairs_per_gpu"] == 64 and wk["total_pairs"] == 128 and wk["value"] == d["value"]
+    assert sg["scaling"] == "strong" and sg["pairs_per_gpu"] == 48 and sg["total_pairs"] == 96 and "configs[3]" in sg["workload"]
+    assert abs(sg["value"] - 96 * 3 / (sg["ms_per_step"] * 3e-3)) / sg["value"] < 1e-3    # the fixed batch per step, whatever N
+    for blk in (wk, sg):
+        assert blk["self_check"]["gathered_blocks_equal_owners"] and blk["self_check"]["ranks"] == 2 and blk["failed_pairs_rank0"] == 0
+    assert d["parity_pinned"] in (True, False) and d["parity_pinned_detail"]
 
 
 @pytest.mark.gpu
@@ -172,7 +182,7 @@ def test_bench_two_ranks_strong_scaling_of_a_fixed_batch():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "3", "--warmup", "1", "--candidates", "c2f", "--scaling", "strong", "--total-pairs", "96", "--no-secondary", "--no-pmc",
+    common = ["--steps", "3", "--warmup", "1", "--candidates", "c2f", "--scaling", "strong", "--total-pairs", "96", "--pairs", "32", "--no-secondary", "--no-pmc",
               "--no-sequences", "--cpu-pairs", "0", "--parity-pairs", "0"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common
@@ -186,6 +196,10 @@ def test_bench_two_ranks_strong_scaling_of_a_fixed_batch():
         assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["pairs_per_gpu"] == per and d["config"]["total_pairs"] == 96
         assert abs(d["value"] - 96 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # the fixed batch per step, whatever N
     assert d2["self_check"]["gathered_blocks_equal_owners"]
+    # `value` is the strong reading here and says so; the weak one (--pairs per GPU, default 4096 -> capped by the test's small --pairs) is beside it
+    assert "configs[3]" in d2["config"]["workload"] and "strong" in d2["config"]["value_is"]
+    assert d2["strong"]["value"] == d2["value"] and d2["weak"]["scaling"] == "weak" and d2["weak"]["self_check"]["gathered_blocks_equal_owners"]
+    assert "weak" not in d1 and "strong" not in d1   # N = 1 is unchanged
 
 
 @pytest.mark.gpu

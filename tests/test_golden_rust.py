@@ -14,69 +14,7 @@ import pytest
 
 from oracle import oracle as O
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = os.path.join(HERE, "golden")
-CASES = ["sparse_128x96_L4", "sparse_odd_167x123_L3", "dense_80x60_L3"]
-FNV_OFFSET, FNV_PRIME, MASK64 = 0xcbf29ce484222325, 0x100000001b3, (1 << 64) - 1
-
-
-def fnv1a(data, h=FNV_OFFSET):
-    for b in bytes(data):
-        h = ((h ^ b) * FNV_PRIME) & MASK64
-    return h
-
-
-def f32_hex(a):
-    return [f"{v:08x}" for v in np.ascontiguousarray(a, np.float32).view(np.uint32).ravel()]
-
-
-def expected_document(case):
-    """The document dump_golden.rs must print for `case` if the oracle equals the reference — same keys, same encodings."""
-    d = np.load(os.path.join(GOLDEN, case + ".npz"))
-    rows, cols, L, mode = int(d["rows"]), int(d["cols"]), int(d["L"]), int(d["mode"])
-    doc = {"case": case}
-    if mode == 0:
-        doc["poses"] = [f32_hex(p) for p in d["poses"]]
-        doc["mask0"] = "".join("1" if v else "0" for v in d["mask0"].ravel())
-        doc["idepth"] = [{"n": int(len(d[f"iz{l}"])), "fnv": f"{fnv1a(np.ascontiguousarray(d[f'iz{l}'], '<f4').tobytes()):016x}"} for l in range(L)]
-    pyr = O.mean_pyramid(d["kf_gray"][0], L)
-    cur = O.mean_pyramid(d["cur_gray"][0], L)
-    doc["pyramid"] = [f"{fnv1a(np.ascontiguousarray(img).tobytes()):016x}" for img in pyr]
-    lm, model = [], np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
-    for l in range(L - 1, -1, -1):
-        st, out, it, e, lam = O.lm_solve(d[f"k{l}"], pyr[l], cur[l], d[f"xy{l}"], d[f"iz{l}"], d[f"jac{l}"], model)
-        if st != 0:
-            lm.append({"level": l, "error": "Error at Cholesky decomposition of hessian"})
-            break
-        model = out
-        lm.append({"level": l, "nb_iter": int(it), "model": f32_hex(out), "energy": f32_hex([e])[0], "lm_coef": f32_hex([lam])[0]})
-    doc["lm"] = lm
-    return doc
-
-
-def compare(doc, exp):
-    """-> list of human-readable differences (empty = bit-identical)."""
-    diffs = []
-    for key in ("poses", "mask0", "idepth", "pyramid"):
-        if key in exp:
-            if key not in doc:
-                diffs.append(f"{key}: missing")
-            elif doc[key] != exp[key]:
-                if key == "poses":
-                    bad = [i for i, (a, b) in enumerate(zip(doc[key], exp[key])) if a != b]
-                    diffs.append(f"poses: pairs {bad} differ (first: rust {doc[key][bad[0]]} oracle {exp[key][bad[0]]})" if bad else "poses: length")
-                elif key == "mask0":
-                    n = sum(a != b for a, b in zip(doc[key], exp[key])) if len(doc[key]) == len(exp[key]) else -1
-                    diffs.append(f"mask0: {n} pixels differ")
-                else:
-                    diffs.append(f"{key}: rust {doc[key]} oracle {exp[key]}")
-    if len(doc.get("lm", [])) != len(exp["lm"]):
-        diffs.append(f"lm: {len(doc.get('lm', []))} levels vs {len(exp['lm'])}")
-    for a, b in zip(doc.get("lm", []), exp["lm"]):
-        for k in b:
-            if a.get(k) != b[k]:
-                diffs.append(f"lm level {b['level']} {k}: rust {a.get(k)} oracle {b[k]}")
-    return diffs
+from oracle.rust_pin import CASES, GOLDEN, compare, expected_document, f32_hex, fnv1a, parity_pinned  # noqa: F401  (the comparator is shared with bench.py / smoke())
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -117,3 +55,13 @@ def test_the_exported_inputs_are_the_fixtures(case):
     for l in range(int(d["L"])):
         assert (np.fromfile(os.path.join(root, f"xy{l}.bin"), "<i4") == d[f"xy{l}"].ravel()).all()
         assert (np.fromfile(os.path.join(root, f"jac{l}.bin"), "<f4").view(np.uint32) == d[f"jac{l}"].astype("<f4").ravel().view(np.uint32)).all()
+
+
+def test_parity_pinned_reports_the_absence_of_the_rust_documents_loudly():
+    """bench.py's `parity_pinned` and smoke()'s last line: False with a reason unless every document exists and compares equal."""
+    pinned, detail = parity_pinned()
+    have = [c for c in CASES if os.path.exists(os.path.join(GOLDEN, "rust", c + ".json"))]
+    if len(have) < len(CASES):
+        assert pinned is False and "INTEGRATION.md" in detail
+    else:
+        assert isinstance(pinned, bool) and detail

@@ -25,7 +25,7 @@ def worker(args):
     import vors_amd as V
     from oracle import oracle as O
     intr = O.scaled_intrinsics(ROWS, COLS)
-    arith = 0 if args.arith == "exact" else 1
+    arith = {"exact": V.ARITH_EXACT, "fused": V.ARITH_FUSED, "reference": V.ARITH_REFERENCE}[args.arith]
     out = {"lib": args.tag}
     for mode, n in (("c2f", args.c2f), ("dense", args.dense), ("dso", args.dso)):
         if n <= 0:

@@ -72,6 +72,7 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     g->huber_delta = cfg->huber_delta;
     g->fused_exact_points = getenv("VORS_FUSED_EXACT_POINTS") ? atoi(getenv("VORS_FUSED_EXACT_POINTS")) : VORS_FUSED_EXACT_POINTS_DEFAULT;
     g->fused_exact_step = getenv("VORS_FUSED_EXACT_STEP") ? atoi(getenv("VORS_FUSED_EXACT_STEP")) : 0;
+    g->ref_rank = (getenv("VORS_REF_RANK") && atoi(getenv("VORS_REF_RANK")) == 0) ? 0 : 1;
     g->fused_small_warp = (getenv("VORS_FUSED_SMALL") && std::string(getenv("VORS_FUSED_SMALL")) == "exact") ? 0 : 1;
     g->S0 = rows * cols;
     int r = rows, c = cols;
@@ -337,7 +338,11 @@ vors_status vors_batch_create_on(int device, const vors_config* cfg, int max_pai
         // column-major records + current pyramid (engine.h RefDensePlanes). Their index arithmetic (i / rows through one multiply-high,
         // lm_reference.hip RefDenseTSrc) is exact while pixels x rows < 2^32 — up to 1920x1080 and beyond; larger frames keep the gathering
         // source on the row-major planes (correct, slow).
-        if (g.arith == VORS_ARITH_REFERENCE && (unsigned long long)g.S0 * (unsigned long long)g.lv[0].rows < (1ull << 32)) {
+        // A level of ONE row (320x240 with 8 levels, 64x32 with 6) has no multiply-high divisor — floor(2^32 / 1) + 1 wraps to 0 and every
+        // pixel of the level would decode as (0, i) instead of (i, 0): such pyramids keep the gathering source as well.
+        bool one_row_level = false;
+        for (int l = 0; l < g.L; ++l) one_row_level = one_row_level || g.lv[l].rows < 2;
+        if (g.arith == VORS_ARITH_REFERENCE && !one_row_level && (unsigned long long)g.S0 * (unsigned long long)g.lv[0].rows < (1ull << 32)) {
             RefDensePlanes& t = b->rec.dense_t;
             if (e == hipSuccess) e = dmalloc(&t.recs, np * ((size_t)g.S0 + g.upper_stride), &b->bytes);
             if (e == hipSuccess) e = dmalloc(&t.n_valid, np * VORS_MAX_LEVELS, &b->bytes);

@@ -38,6 +38,8 @@ struct Geom {
     // is evaluated in the EXACT arithmetic (lm_kernels.hip lm_track_kernel); fused_exact_step != 0 also takes its step() with lm_step
     int fused_exact_points, fused_exact_step;
     int fused_small_warp;  // candidate-list modes: such a level takes only (u, v) from the reference's warp chain (lm_kernels.hip fused_stage_b<XW>)
+    int ref_rank;       // REFERENCE arithmetic, coarse-to-fine: rank the keyframe kernel's staged regions directly (lm_reference.hip); resolved ONCE per
+                        // handle from VORS_REF_RANK (development knob) so that the keyframe stage and the sort take the same decision
     int wide_loads_ok;  // set per launch: the caller's buffers are 16-byte aligned, so the dense quad source may use wide loads
     // Masked launches of the keyframe stage (vors_trackers: per-sequence keyframe promotion on the device). When sel_list is set, index k
     // of a kernel's pair dimension addresses pair sel_list[k] for k < *sel_count and nothing beyond (device_common.h select_pair).

@@ -708,9 +708,12 @@ struct RefLmAhead {
     Iso cand;
     bool ok, valid;
 };
+__device__ __forceinline__ bool ref_lm_ahead_valid(const RefLm& s) {
+    return s.started && !(s.nb_iter > 20);  // (a rejected evaluation with too many iterations stops the level instead)
+}
 __device__ __forceinline__ RefLmAhead ref_lm_step_ahead(const RefLm& s) {
     RefLmAhead a;
-    a.valid = s.started && !(s.nb_iter > 20);  // (a rejected evaluation with too many iterations stops the level instead)
+    a.valid = ref_lm_ahead_valid(s);
     a.ok = false;
     a.cand = s.cand;
     if (a.valid) a.ok = refw_step(s.kept, s.cur_model, s.lm_coef * 10.0f, &a.cand);
@@ -1221,27 +1224,41 @@ static int refw_waves_per_block(int n_pairs) {
 // (per CU: 16 wavefronts, 160 KB of LDS at 2 (W - 1) blocks of 7.6 KB per workgroup — MI355X: 256 pairs with 8, 512 with 5, 768 with 4,
 // 1280 with 3); a batch that needs a second round of workgroups is slower than a thinner workgroup for everyone (tools/coop_sweep.py: 320
 // pairs 0.83 ms per step with 8 wavefronts, 0.65 with 5; 1024 pairs 1.52 with 5, 1.22 with 3). Beyond that: one wavefront per pair.
+// What the CURRENT device offers a workgroup kernel: compute units and LDS per CU (queried per call — cheap, cached by the runtime — because a
+// process may hold handles on devices of different sizes; MI355X: 256 CUs, 160 KB).
+struct RefcDevice {
+    int cus;
+    size_t lds_per_cu;
+};
+static RefcDevice refc_device() {
+    int dev = 0, cus = 0, lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 64 * 1024;
+    int lds_cu = 0;  // (some runtimes report the 64 KB default per block and the real size per multiprocessor: a workgroup may take all of it)
+    if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && lds_cu > lds) lds = lds_cu;
+    (void)hipGetLastError();
+    return RefcDevice{cus, (size_t)lds};
+}
+static size_t refc_lds_bytes(int waves) { return (size_t)2 * (waves - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared); }
 static int refc_waves_per_pair(int n_pairs, bool dense) {
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
+    const RefcDevice d = refc_device();
     int w = 0;
     for (int cand : {8, 5, 4, 3}) {
-        const size_t lds = (size_t)2 * (cand - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
-        const long long per_cu = std::min<long long>(16 / cand, (long long)((size_t)160 * 1024 / lds));
-        if (per_cu * cus >= n_pairs) {
+        const size_t lds = refc_lds_bytes(cand);
+        if (lds > d.lds_per_cu) continue;  // (a device with less LDS than gfx950: thinner workgroups)
+        const long long per_cu = std::min<long long>(16 / cand, (long long)(d.lds_per_cu / lds));
+        if (per_cu * d.cus >= n_pairs) {
             w = cand;
             break;
         }
     }
     // dense: two producers do not keep up with the chains of 409,600 points (1024 pairs: 20.5 ms per step with 3 wavefronts, 18.9 with 5 in
     // two rounds of workgroups) — five up to 1280 pairs as before
-    if (dense && w < 4 && n_pairs <= 5 * cus) w = 5;
+    if (dense && w < 4 && n_pairs <= 5 * d.cus && refc_lds_bytes(5) <= d.lds_per_cu) w = 5;
     if (const char* e = getenv("VORS_REF_COOP")) {
         const int v = atoi(e);
-        if (v == 0 || (v >= 2 && v <= 8)) w = v;
+        if (v == 0 || (v >= 2 && v <= 8 && refc_lds_bytes(v) <= d.lds_per_cu)) w = v;
     }
     return w;
 }
@@ -1284,7 +1301,8 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         // (a launch may ask for more than 64 KB of dynamic LDS only after the kernel has been told so; per device, hence not cached in a static)
 #define VORS_REF_LAUNCH(K)                                                                                                                  \
     do {                                                                                                                                    \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            break; /* (the error stays pending: the caller's hipGetLastError reports it against this launch) */ \
         hipLaunchKernelGGL(K, dim3(n_pairs), dim3(64 * coop), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
                            kf_poses7, out_poses7, out_status, out_stats, n_pairs, 0);                                                      \
     } while (0)
@@ -1334,7 +1352,8 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
         const size_t lds = (size_t)2 * (hw - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared);
 #define VORS_REF_LAUNCH(K)                                                                                                                  \
     do {                                                                                                                                    \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            break; \
         hipLaunchKernelGGL(K, dim3(n_pairs - ho_after), dim3(64 * hw), lds, s, g, cur.level0, cur.upper, kf.level0, kf.upper, kf_depth, rec, prev_poses7, \
                            kf_poses7, out_poses7, out_status, out_stats, n_pairs, 1);                                                      \
     } while (0)
@@ -1911,8 +1930,7 @@ __global__ __launch_bounds__(RANK_BLOCK) void rank_regions_kernel(Geom g, Record
 // VORS_REF_RANK=0 keeps the two-kernel form (A/B, tests).
 bool ref_rank_from_regions(const Geom& g, const Records& rec) {
     if (g.arith != VORS_ARITH_REFERENCE || g.mode != VORS_CANDIDATES_COARSE_TO_FINE || !rec.stage || rec.n_regions > RANK_MAX_REGIONS) return false;
-    if (const char* e = getenv("VORS_REF_RANK"))
-        if (atoi(e) == 0) return false;
+    if (!g.ref_rank) return false;  // (VORS_REF_RANK=0, resolved when the handle was created: capi.cpp build_geom)
     for (int l = 0; l < g.L; ++l)
         if (g.lv[l].n_slots > RANK_U_MAX * RANK_BLOCK || g.lv[l].n_slots >= 65536) return false;
     return true;
