@@ -1,0 +1,9 @@
+cd /root/repo; mkdir -p gpurun_out/r06
+out=gpurun_out/r06/kf_batch.log; : > $out
+V=$PWD/visual-odometry-rs_amd/vors_amd
+for rep in 1 2; do for tag in kb1 kb2 kb4; do
+  echo "== $tag (rep $rep)" >> $out
+  VORS_HIP_LIB=$V/libvors_hip_$tag.so MODES=c2f python tools/stage_times.py reference 512 4096 2>&1 | grep pairs >> $out
+done; done
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference.py tests/test_gpu_pyramid.py tests/test_gpu_trackers.py -x -q 2>&1 | tail -3 >> $out
+cat $out

@@ -252,6 +252,63 @@ __device__ __forceinline__ void write_empty(const Records& rec, size_t slot) {
 // (inverse_depth.rs:81-98; at most two known children per parent here, so the [a,b,c,d] order cannot matter).
 // ------------------------------------------------------------------------------------------------------------
 #define KF_WAVES 4
+#ifndef VORS_KF_BATCH
+#define VORS_KF_BATCH 2  // chunks of 64 (node, child) items whose gradient gathers travel together (1 = one round trip per chunk: round 5; measured 1 / 2 / 4: keyframe stage 1.143 / 1.112 / 1.116 ms per 4096 pairs)
+#endif
+// grad_tmpl_at (device_common.h) in two halves — the REQUESTS for what a pixel's gradient and grey level are made of, and their decoding —
+// so that the requests of several independent items can be in flight at once. L0: the pixel is of level 0 (centred differences,
+// gradient.rs:15-33), else of a level >= 1 (2x2 block gradient of the next finer level, gradient.rs:74-93; its grey level is that block's
+// floored mean, multires.rs:21-31). Same loads, same integer arithmetic as grad_tmpl_at.
+struct KfGradRaw {
+    uint32_t w0, w1, w2;
+};
+template <bool L0>
+__device__ __forceinline__ KfGradRaw kf_grad_request(const Geom& g, const uint8_t* level0, const uint8_t* upper, int pair, int l, int x, int y) {
+    KfGradRaw r;
+    if (L0) {
+        const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+        const uint8_t* p = level0 + (size_t)pair * g.S0;
+        const unsigned o = __umul24((unsigned)y, (unsigned)cols) + (unsigned)x;
+        const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
+        const unsigned dy = interior ? (unsigned)cols : 0u;
+        const unsigned base = interior ? o - 1u : min(o, (unsigned)g.S0 - 4u);  // left, centre, right as one (unaligned) dword
+        __builtin_memcpy(&r.w0, p + base, 4);
+        r.w1 = p[o - dy];
+        r.w2 = p[o + dy];
+    } else {
+        const int fc = g.lv[l - 1].cols;
+        const uint8_t* pb = level_ptr(g, level0, upper, pair, l - 1);
+        const unsigned o = __umul24((unsigned)(2 * y), (unsigned)fc) + (unsigned)(2 * x);
+        uint16_t r0, r1;  // the 2x2 block as two (possibly unaligned) 16-bit loads
+        __builtin_memcpy(&r0, pb + o, 2);
+        __builtin_memcpy(&r1, pb + (o + (unsigned)fc), 2);
+        r.w0 = r0;
+        r.w1 = r1;
+        r.w2 = 0;
+    }
+    return r;
+}
+template <bool L0>
+__device__ __forceinline__ void kf_grad_decode(const Geom& g, const KfGradRaw& r, int x, int y, int* gx, int* gy, int* tm) {
+    if (L0) {
+        const int rows = g.lv[0].rows, cols = g.lv[0].cols;
+        const unsigned o = __umul24((unsigned)y, (unsigned)cols) + (unsigned)x;
+        const bool interior = !(x == 0 || y == 0 || x == cols - 1 || y == rows - 1);
+        const unsigned base = interior ? o - 1u : min(o, (unsigned)g.S0 - 4u);
+        const uint32_t w = r.w0;
+        const int c0 = (int)((w >> (8u * (interior ? 1u : o - base))) & 0xffu);
+        const int l0 = interior ? (int)(w & 0xffu) : c0, r0 = interior ? (int)((w >> 16) & 0xffu) : c0;
+        const int u0 = (int)r.w1, d0 = (int)r.w2;
+        *tm = c0;
+        *gx = (r0 - l0) / 2;  // borders: the taps alias the centre pixel -> 0, like gradient.rs:15-33
+        *gy = (d0 - u0) / 2;
+    } else {
+        const int a = r.w0 & 0xff, c = r.w0 >> 8, b = r.w1 & 0xff, d = r.w1 >> 8;
+        *gx = (c + d - a - b) / 2;
+        *gy = (b - a + d - c) / 2;
+        *tm = (a + b + c + d) >> 2;
+    }
+}
 // KF_R roots per wavefront: the early tree steps have only 4 * 2^k (node, child) items per root, so several roots share
 // a wavefront (more lanes busy, more independent loads in flight per wave, 1/KF_R as many waves).
 // The wavefronts of a keyframe workgroup never share LDS (each owns the tree nodes of its own roots), so the steps of the descent
@@ -260,11 +317,19 @@ __device__ __forceinline__ void kf_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template <int KF_R>
+#ifndef VORS_KF_PAD
+#define VORS_KF_PAD 1  // one word of padding per root's tree: the roots of a wavefront no longer sit 2^L words apart — all in the same LDS
+                       // banks (round 6 counters: 46 % of the kernel's LDS cycles were bank conflicts)
+#endif
+__host__ __device__ inline int kf_nodes(int L) { return (1 << L) + VORS_KF_PAD; }
+// LC: the number of pyramid levels as a compile-time constant (6 and 7: BASELINE's configurations), 0 = read it from the geometry. With a
+// constant the level loops unroll, the slot arithmetic (capacities, offsets, shifts) folds into immediates and the chunk loops become
+// straight-line code — the kernel is bound by the instructions a wavefront issues, a third of them scalar loop and address bookkeeping.
+template <int KF_R, int LC>
 __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, const uint8_t* __restrict__ kf0,
                                                                          const uint8_t* __restrict__ kfu,
                                                                          const uint16_t* __restrict__ depth, Records rec) {
-    const int NODES = 1 << g.L;  // >= 2^L - 1 tree nodes per root
+    const int NODES = kf_nodes(LC ? LC : g.L);  // >= 2^L - 1 tree nodes per root
     extern __shared__ __attribute__((aligned(16))) char kf_smem[];
     uint32_t* s_xy = reinterpret_cast<uint32_t*>(kf_smem);  // [KF_WAVES][KF_R][NODES]
     uint32_t* s_gr = s_xy + KF_WAVES * KF_R * NODES;
@@ -275,7 +340,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     if (pair < 0) return;
     const int n_roots = g.root_rows * g.root_cols;
     const int root0 = (blockIdx.x * KF_WAVES + wave) * KF_R;  // first root of this wavefront
-    const int L = g.L;
+    const int L = LC ? LC : g.L;
     uint32_t* xy = s_xy + wave * KF_R * NODES;
     uint32_t* gr = s_gr + wave * KF_R * NODES;
     float* sd = s_d + wave * KF_R * NODES;
@@ -297,44 +362,72 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     kf_wave_sync();
 
     // ---- top-down selection: level l -> l-1. Items = (root, node k, child c); the 4 children of a node sit in one quad.
+    // Round 6: the descent is a chain of dependent gathers (the children's gradients need the parents the previous step selected), and at the
+    // two finest steps a wavefront has 2 and 4 chunks of 64 items to look at: their gathers are REQUESTED TOGETHER (kf_grad_request, at most
+    // VORS_KF_BATCH chunks) and only then decoded and ranked — one memory round trip per batch instead of one per chunk. Worth 3 % of the stage, no more:
+    // the kernel is bound by the ~1500 instructions a wavefront issues for its 4 roots (profiles/r06_experiments), not by these round trips.
     const uint32_t thresh = (uint32_t)g.thresh & 0xffffu;
+#pragma unroll
     for (int l = L - 1; l >= 1; --l) {
         const int lc = L - 1 - l, cap = 1 << lc;  // (a power of two: slot arithmetic by shifts, not divisions)
         const int off = cap - 1, offc = 2 * cap - 1;
         const int items = KF_R * cap * 4;
-        for (int base = 0; base < items; base += 64) {
-            const int t = base + lane;
-            const bool in = t < items;
-            const int rl = in ? (t >> 2) >> lc : 0;  // root slot inside the wavefront
-            const int k = (t >> 2) & (cap - 1), c = lane & 3;
-            const uint32_t pxy = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
-            const bool pvalid = pxy != VORS_INVALID_XY;
-            const int cx = 2 * (int)(pxy & 0xffffu) + (c >> 1), cy = 2 * (int)(pxy >> 16) + (c & 1);
-            int gx = 0, gy = 0, tm = 0;
-            if (pvalid) grad_tmpl_at(g, kf0, kfu, pair, l - 1, cx, cy, &gx, &gy, &tm);
-            const uint32_t g2 = (uint32_t)(gx * gx + gy * gy) & 0xffffu;  // `as u16` wrap, gradient.rs:39-43
-            // The four children of a node sit in one quad. Stable ranking (a later child wins a tie: ties rank by child index) = ranking
-            // of the DISTINCT keys (g2 << 2 | child); the quad's keys by DPP quad broadcasts, sorted by a 5-exchange network.
-            const uint32_t key = (g2 << 2) | (uint32_t)c;
-            uint32_t k0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x00, 0xf, 0xf, true);
-            uint32_t k1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x55, 0xf, 0xf, true);
-            uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xaa, 0xf, 0xf, true);
-            uint32_t k3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xff, 0xf, 0xf, true);
-            {
-                uint32_t lo, hi;
-                lo = min(k0, k1); hi = max(k0, k1); k0 = lo; k1 = hi;
-                lo = min(k2, k3); hi = max(k2, k3); k2 = lo; k3 = hi;
-                lo = min(k0, k2); hi = max(k0, k2); k0 = lo; k2 = hi;
-                lo = min(k1, k3); hi = max(k1, k3); k1 = lo; k3 = hi;
-                lo = min(k1, k2); hi = max(k1, k2); k1 = lo; k2 = hi;
+        const bool child0 = l == 1;  // the children are pixels of level 0 (centred gradients), else of a level above (block gradients)
+        for (int base = 0; base < items; base += 64 * VORS_KF_BATCH) {
+            uint32_t pxy_b[VORS_KF_BATCH];
+            KfGradRaw raw_b[VORS_KF_BATCH];
+#pragma unroll
+            for (int b = 0; b < VORS_KF_BATCH; ++b) {
+                const int t = base + 64 * b + lane;
+                const bool in = t < items;
+                const int rl = in ? (t >> 2) >> lc : 0;  // root slot inside the wavefront
+                const int k = (t >> 2) & (cap - 1), c = lane & 3;
+                pxy_b[b] = in ? xy[rl * NODES + off + k] : VORS_INVALID_XY;
+                const bool pvalid = pxy_b[b] != VORS_INVALID_XY;
+                const int cx = pvalid ? 2 * (int)(pxy_b[b] & 0xffffu) + (c >> 1) : 0, cy = pvalid ? 2 * (int)(pxy_b[b] >> 16) + (c & 1) : 0;
+                // (an item without a parent requests pixel (0, 0): a safe address, its result is replaced by zeros below)
+                if (base + 64 * b < items) raw_b[b] = child0 ? kf_grad_request<true>(g, kf0, kfu, pair, l - 1, cx, cy) : kf_grad_request<false>(g, kf0, kfu, pair, l - 1, cx, cy);
             }
-            const uint32_t second = k2 >> 2, third = k1 >> 2;                 // the values of rank 2 and rank 1
-            const bool keep2 = second > ((third + thresh) & 0xffffu);         // u16 wrapping add, coarse_to_fine.rs:85
-            if (in && key >= k2) {  // rank 3 (the best: always kept) -> slot 2k, rank 2 (kept if it stands out) -> slot 2k + 1
-                const bool best = key == k3;
-                const int dst = rl * NODES + offc + 2 * k + (best ? 0 : 1);
-                xy[dst] = (pvalid && (best || keep2)) ? ((uint32_t)cx | ((uint32_t)cy << 16)) : VORS_INVALID_XY;
-                gr[dst] = slim_pack_tg(tm, gx, gy);
+#pragma unroll
+            for (int b = 0; b < VORS_KF_BATCH; ++b) {
+                if (base + 64 * b >= items) break;  // (uniform)
+                const int t = base + 64 * b + lane;
+                const bool in = t < items;
+                const int rl = in ? (t >> 2) >> lc : 0;
+                const int k = (t >> 2) & (cap - 1), c = lane & 3;
+                const uint32_t pxy = pxy_b[b];
+                const bool pvalid = pxy != VORS_INVALID_XY;
+                const int cx = 2 * (int)(pxy & 0xffffu) + (c >> 1), cy = 2 * (int)(pxy >> 16) + (c & 1);
+                int gx = 0, gy = 0, tm = 0;
+                if (child0) kf_grad_decode<true>(g, raw_b[b], pvalid ? cx : 0, pvalid ? cy : 0, &gx, &gy, &tm);
+                else kf_grad_decode<false>(g, raw_b[b], pvalid ? cx : 0, pvalid ? cy : 0, &gx, &gy, &tm);
+                gx = pvalid ? gx : 0;
+                gy = pvalid ? gy : 0;
+                tm = pvalid ? tm : 0;
+                const uint32_t g2 = (uint32_t)(gx * gx + gy * gy) & 0xffffu;  // `as u16` wrap, gradient.rs:39-43
+                // The four children of a node sit in one quad. Stable ranking (a later child wins a tie: ties rank by child index) = ranking
+                // of the DISTINCT keys (g2 << 2 | child); the quad's keys by DPP quad broadcasts, sorted by a 5-exchange network.
+                const uint32_t key = (g2 << 2) | (uint32_t)c;
+                uint32_t k0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x00, 0xf, 0xf, true);
+                uint32_t k1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x55, 0xf, 0xf, true);
+                uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xaa, 0xf, 0xf, true);
+                uint32_t k3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xff, 0xf, 0xf, true);
+                {
+                    uint32_t lo, hi;
+                    lo = min(k0, k1); hi = max(k0, k1); k0 = lo; k1 = hi;
+                    lo = min(k2, k3); hi = max(k2, k3); k2 = lo; k3 = hi;
+                    lo = min(k0, k2); hi = max(k0, k2); k0 = lo; k2 = hi;
+                    lo = min(k1, k3); hi = max(k1, k3); k1 = lo; k3 = hi;
+                    lo = min(k1, k2); hi = max(k1, k2); k1 = lo; k2 = hi;
+                }
+                const uint32_t second = k2 >> 2, third = k1 >> 2;                 // the values of rank 2 and rank 1
+                const bool keep2 = second > ((third + thresh) & 0xffffu);         // u16 wrapping add, coarse_to_fine.rs:85
+                if (in && key >= k2) {  // rank 3 (the best: always kept) -> slot 2k, rank 2 (kept if it stands out) -> slot 2k + 1
+                    const bool best = key == k3;
+                    const int dst = rl * NODES + offc + 2 * k + (best ? 0 : 1);
+                    xy[dst] = (pvalid && (best || keep2)) ? ((uint32_t)cx | ((uint32_t)cy << 16)) : VORS_INVALID_XY;
+                    gr[dst] = slim_pack_tg(tm, gx, gy);
+                }
             }
         }
         kf_wave_sync();
@@ -359,6 +452,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     }
     kf_wave_sync();
     // ---- bottom-up fusion (strategy_dso_mean, inverse_depth.rs:81-98)
+#pragma unroll
     for (int l = 1; l < L; ++l) {
         const int cap = 1 << (L - 1 - l);
         const int off = cap - 1, offc = 2 * cap - 1;
@@ -385,6 +479,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void keyframe_sparse_kernel(Geom g, 
     // KF_R * cap contiguous slots of each level in the STAGING grid; usable points are compacted to the front of that region (fixed
     // order: by root, then tree slot) and the region's count is published; compact_regions_kernel then packs the regions of a pair.
     const int region = blockIdx.x * KF_WAVES + wave;
+#pragma unroll
     for (int l = 0; l < L; ++l) {
         const int cap = 1 << (L - 1 - l), off = cap - 1;
         const int n_here = min(KF_R, max(0, n_roots - root0)) * cap;  // slots of this region that exist
@@ -813,7 +908,7 @@ void launch_zero_ints(const Geom& g, int* base, int stride, int n_pairs, hipStre
 static int keyframe_roots_per_wave(const Geom& g) {
     static int kf_r = getenv("VORS_KF_R") ? atoi(getenv("VORS_KF_R")) : 4;  // roots per wavefront (tuning knob)
     int r = kf_r >= 8 ? 8 : (kf_r >= 4 ? 4 : (kf_r >= 2 ? 2 : 1));
-    while (r > 1 && (size_t)KF_WAVES * r * (1 << g.L) * 16 > 64 * 1024) r >>= 1;  // stay inside the 64 KiB a workgroup may ask for
+    while (r > 1 && (size_t)KF_WAVES * r * kf_nodes(g.L) * 16 > 64 * 1024) r >>= 1;  // stay inside the 64 KiB a workgroup may ask for
     return r;
 }
 void keyframe_region_geometry(const Geom& g, int* kf_r, int* n_regions) {
@@ -851,11 +946,18 @@ void launch_keyframe(const Geom& g, Pyramid kf, const uint16_t* depth, Records r
         // the region geometry the handle was sized for (keyframe_region_geometry at create(), capi.cpp) is the single source of truth
         const int r = rec.kf_r;
         dim3 grid(rec.n_regions / KF_WAVES, n_pairs);
-        const size_t lds = (size_t)KF_WAVES * r * (1 << g.L) * 16;
-        if (r == 8) hipLaunchKernelGGL(keyframe_sparse_kernel<8>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
-        else if (r == 4) hipLaunchKernelGGL(keyframe_sparse_kernel<4>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
-        else if (r == 2) hipLaunchKernelGGL(keyframe_sparse_kernel<2>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
-        else hipLaunchKernelGGL(keyframe_sparse_kernel<1>, grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        const size_t lds = (size_t)KF_WAVES * r * kf_nodes(g.L) * 16;
+#ifndef VORS_KF_CONST_L
+#define VORS_KF_CONST_L 1  // (0: every launch reads the level count from the geometry — A/B)
+#endif
+        if (r == 8 && g.L == 6 && VORS_KF_CONST_L) hipLaunchKernelGGL((keyframe_sparse_kernel<8, 6>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 2 && g.L == 6 && VORS_KF_CONST_L) hipLaunchKernelGGL((keyframe_sparse_kernel<2, 6>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 8) hipLaunchKernelGGL((keyframe_sparse_kernel<8, 0>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 4 && g.L == 6 && VORS_KF_CONST_L) hipLaunchKernelGGL((keyframe_sparse_kernel<4, 6>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 4 && g.L == 7 && VORS_KF_CONST_L) hipLaunchKernelGGL((keyframe_sparse_kernel<4, 7>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 4) hipLaunchKernelGGL((keyframe_sparse_kernel<4, 0>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else if (r == 2) hipLaunchKernelGGL((keyframe_sparse_kernel<2, 0>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
+        else hipLaunchKernelGGL((keyframe_sparse_kernel<1, 0>), grid, dim3(64 * KF_WAVES), lds, s, g, kf.level0, kf.upper, depth, rec);
         // (REFERENCE arithmetic: launch_sort_colmajor, which every caller runs next, packs AND orders the regions in one pass — lm_reference.hip)
         if (!ref_rank_from_regions(g, rec))
             hipLaunchKernelGGL(compact_regions_kernel, dim3(n_pairs <= 1024 ? g.L : 1, n_pairs), dim3(256), 0, s, g, rec);
