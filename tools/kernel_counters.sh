@@ -1,4 +1,4 @@
-# usage: bash tools/r06_counters.sh <candidates> <arith> <outfile>   — SQ instruction-mix counters per kernel of 3 steps (1 warm-up + 2) at 4096 pairs
+# usage: bash tools/kernel_counters.sh <candidates> <arith> <outfile>   — SQ instruction-mix counters per kernel of 3 steps (1 warm-up + 2) at 4096 pairs
 cd /root/repo; mkdir -p gpurun_out/r06
 cand=$1; arith=$2; out=gpurun_out/r06/$3; : > $out
 export TMPDIR=/tmp

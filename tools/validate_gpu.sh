@@ -1,4 +1,4 @@
-# round 6: full GPU suite + the default bench line (what the driver runs at round end)
+# full GPU suite + the default bench line (what the driver runs at round end)
 cd /root/repo
 mkdir -p gpurun_out/r06
 ( time python -m pytest tests -m gpu -x -q ) > gpurun_out/r06/gputest.log 2>&1
