@@ -172,7 +172,7 @@ def arith_id(V, name):
 
 
 class Workload:
-    def __init__(self, V, args, mode, device, seed0, pairs=None):
+    def __init__(self, V, args, mode, device, seed0, pairs=None, batch=True):
         self.V, self.args, self.mode = V, args, mode
         n, rows, cols, L = pairs or args.pairs, args.rows, args.cols, args.levels
         self.n = n
@@ -184,7 +184,7 @@ class Workload:
         if mode == "dso":
             seed0 |= 1 << 63  # piecewise-constant texture: the DSO thresholds reject the smooth texture entirely
         self.cfg = cfg
-        self.batch = V.Batch(cfg, n, rows, cols)
+        self.batch = V.Batch(cfg, n, rows, cols) if batch else None   # (batch=False: inputs / outputs only — the ring owns the handles)
         self.kg, self.kd, self.cg, _, self.gt = V.synth_render_pairs(seed0, n, rows, cols, self.intr, device=device)
         self.poses = torch.zeros((n, 7), dtype=torch.float32, device=device)
         self.status = torch.zeros(n, dtype=torch.int32, device=device)
@@ -239,6 +239,66 @@ def timed_run(work, steps, warmup, world, packed, gathered):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+class Ring:
+    """A continuous feed through vors_pipeline_* (the C ABI's throughput mode): `depth` batch handles on internal streams, consecutive steps on
+    consecutive handles; `depth` sets of inputs / outputs so that steps in flight share no buffer. Each step is still ONE full pass of the hot
+    path over its own batch; what changes is that step k + 1's pyramids and keyframe stage run under step k's LM stage and its straggler tail."""
+
+    def __init__(self, V, args, mode, device, seed0, pairs, depth):
+        self.depth, self.n = depth, pairs
+        self.works = [Workload(V, args, mode, device, seed0 + k * pairs, pairs=pairs, batch=False) for k in range(depth)]
+        self.pipe = V.Pipeline(self.works[0].cfg, pairs, args.rows, args.cols, depth=depth)
+        self.tickets = {}
+
+    def submit(self, i):
+        w = self.works[i % self.depth]
+        self.tickets[i] = self.pipe.submit(w.kg, w.kd, w.cg, w.poses, w.status, w.stats)
+
+    def run(self, steps, warmup, after_step=None, barrier=None):
+        """-> seconds for `steps` steps (after `warmup` untimed ones); after_step(i, work) — e.g. the all-gather of a rank's results — is
+        called for step i once it has completed in stream order, `depth - 1` steps behind the submissions."""
+        def feed(first, count):
+            for i in range(first, first + count):
+                self.submit(i)
+                j = i - (self.depth - 1)
+                if after_step is not None and j >= first:
+                    self.pipe.wait(self.tickets.pop(j))
+                    after_step(j, self.works[j % self.depth])
+            for j in range(max(first, first + count - (self.depth - 1)), first + count):
+                if after_step is not None:
+                    self.pipe.wait(self.tickets.pop(j))
+                    after_step(j, self.works[j % self.depth])
+            self.pipe.drain()
+            self.tickets.clear()
+        feed(0, max(warmup, self.depth))
+        torch.cuda.synchronize()
+        if barrier is not None:   # (N > 1: every rank starts and stops the clock behind a barrier, like timed_run)
+            barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feed(1000, steps)
+        torch.cuda.synchronize()
+        if barrier is not None:
+            barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
+def ring_block(V, args, mode, device, seed0, pairs, steps, single_ms=None, depth=3):
+    """Throughput of `pairs`-pair steps fed through a ring of `depth` handles (Ring) -> block for the JSON line."""
+    r = Ring(V, args, mode, device, seed0, pairs, depth)
+    # (a ring fills and drains once per measurement — about one step's worth: enough steps that the figure is the rate of the feed, within
+    # ~3 s of GPU time)
+    if single_ms:
+        steps = max(steps, min(100, int(3000.0 / max(single_ms, 1e-3))))
+    dt = r.run(steps, 2)
+    blk = {"ring": depth, "steps": steps, "value": round(pairs * steps / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt / steps * 1e3, 4)}
+    if single_ms:
+        blk["gain_over_single_stream"] = round(single_ms / (dt / steps * 1e3), 3)
+    del r
+    return blk
 
 
 def host_pairs(work, n):
@@ -575,6 +635,12 @@ def reference_block(V, args, device, seed0, ring):
                                 "lm_kernel_ms": round(float(w5.batch.kernel_times("lm")[-steps:].mean()), 5),
                                 "step_time_ratio_vs_headline_batch": round((dt / steps) / (dt5 / steps), 3)}
             del w5
+            # throughput mode (ring of 3 handles, see `pipelined` of the headline): the default arithmetic gains most — the one-wavefront kernel's
+            # straggler tail and the dependent chains of a small batch are what the next step fills
+            blk["pipelined"] = ring_block(V, a, mode, device, seed0, a.pairs, steps, dt / steps * 1e3)
+            blk["batch_512"]["pipelined"] = ring_block(V, a5, mode, device, seed0, 512, steps, dt5 / steps * 1e3)
+            blk["batch_512"]["step_time_ratio_pipelined_vs_pipelined_headline_batch"] = round(
+                blk["pipelined"]["ms_per_step"] / blk["batch_512"]["pipelined"]["ms_per_step"], 3)
         out[mode] = blk
     return out
 
@@ -845,6 +911,29 @@ def main():
                     "scaling": kind, "value": round(total * args.steps / dt_k, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt_k / args.steps * 1e3, 4),
                     "pairs_per_gpu": per, "total_pairs": total, "failed_pairs_rank0": int((work.status != 0).sum().item()), "self_check": check}
         out[args.scaling] = scaling_block(args.scaling, main_w, dt, out["self_check"])
+
+        def pipelined_scaling(a_k, kind):
+            # the same per-rank share as a continuous feed through a ring of 3 handles (vors_pipeline_*), the all-gather of a step's 8 f32 per
+            # pair issued once that step has completed in stream order (two steps behind the submissions); barrier + MAX over ranks as above
+            import torch.distributed as dist
+            r = Ring(V, a_k, args.candidates, device, 0x5EED0000 + rank * a_k.pairs, a_k.pairs, 3)
+            pk = torch.zeros((a_k.pairs, 8), dtype=torch.float32, device=device)
+            ga = torch.zeros((world * a_k.pairs, 8), dtype=torch.float32, device=device)
+            from vors_amd.distributed import gather_packed
+
+            def after(i, w):
+                pk[:, :7] = w.poses
+                pk[:, 7] = w.status
+                gather_packed(pk, out=ga)
+            dt_p = r.run(args.steps, max(args.warmup, 3), after, barrier=dist.barrier)
+            t = torch.tensor([dt_p], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_p = float(t.item())
+            total = args.total_pairs if kind == "strong" else world * a_k.pairs
+            del r
+            return {"ring": 3, "value": round(total * args.steps / dt_p, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt_p / args.steps * 1e3, 4),
+                    "note": "vors_pipeline_* ring of 3 handles per rank + the per-step all-gather; not `value`"}
+        out[args.scaling]["pipelined"] = pipelined_scaling(args, args.scaling)
         other = "strong" if args.scaling == "weak" else "weak"
         import copy
         a2 = copy.copy(args)
@@ -854,8 +943,11 @@ def main():
         gathered2 = torch.zeros((world * a2.pairs, 8), dtype=torch.float32, device=device)
         dt_o = timed_run(w2, args.steps, args.warmup, world, packed2, gathered2)
         out[other] = scaling_block(other, w2, dt_o, multi_gpu_self_check(a2, w2, packed2, gathered2, rank, world))
+        del w2
+        w2 = None
+        out[other]["pipelined"] = pipelined_scaling(a2, other)
         out["config"]["value_is"] = f"`{args.scaling}` (see the `weak` and `strong` blocks; `strong` is BASELINE configs[3] as written)"
-        del w2, packed2, gathered2
+        del packed2, gathered2
     if rank == 0 and world == 1:
         if not args.no_secondary:
             # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload, and BASELINE config 4's per-GPU share on 8 GPUs (512)
@@ -915,32 +1007,33 @@ def main():
                     else:
                         out["parity_dso"] = pb
                 del w2
-            # ---- the same workload with steps alternating between TWO handles on two HIP streams (each step is still one full pass over its
-            # own batch of `pairs` pairs; the GPU overlaps the tail of one step — dependent straggler rounds, last workgroups of per-pair kernels — with the
-            # VALU-bound body of the next). `value` above stays the single-stream figure: its stage times and roofline are self-consistent.
-            # (vors_pipeline_*, the C ABI's throughput mode: a ring of two handles on internal streams; a second set of inputs and outputs so
-            # that consecutive steps share no buffer)
-            w3 = Workload(V, args, args.candidates, device, seed0 + args.pairs)
-            pipe = V.Pipeline(main_w.cfg, args.pairs, args.rows, args.cols, depth=2)
-            both = [main_w, w3]
-
-            def alt(i):
-                w = both[i & 1]
-                pipe.submit(w.kg, w.kd, w.cg, w.poses, w.status, w.stats)
-            for i in range(2 * max(args.warmup, 1)):
-                alt(i)
-            pipe.drain()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                alt(i)
-            pipe.drain()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t0
-            out["pipelined_two_streams"] = {"value": round(args.pairs * args.steps / dt3, 2), "unit": "frame-pairs/s",
-                                            "ms_per_step": round(dt3 / args.steps * 1e3, 4),
-                                            "note": "vors_pipeline_* with depth 2: steps alternate between two batch handles on two internal streams; not the headline"}
-            del pipe, w3
+            # ---- THROUGHPUT MODE (vors_pipeline_*, the C ABI's ring of batch handles on internal streams): the same steps as a continuous feed,
+            # consecutive steps on consecutive handles — each step is still one full pass over its own batch; step k + 1's pyramids and keyframe
+            # stage run under step k's LM stage and its straggler tail. `value` above stays the single-stream figure (its stage times and
+            # roofline are self-consistent); this is what a deployment that feeds batches back to back gets, and what BASELINE config 4's
+            # per-GPU share (512 pairs) needs: a 512-pair step alone leaves most of the chip idle.
+            single_ms = dt / args.steps * 1e3
+            out["pipelined_two_streams"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=2)
+            out["pipelined"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=3)
+            out["pipelined"]["note"] = ("vors_pipeline_* with a ring of 3 handles (pipelined_two_streams: ring of 2); a step = one full pass over its "
+                                        "own batch; not the headline")
+            if "batch_512" in out and args.pairs != 512:
+                out["batch_512"]["pipelined"] = ring_block(V, args, args.candidates, device, seed0, 512, args.steps, out["batch_512"]["ms_per_step"])
+                out["batch_512"]["step_time_ratio_pipelined_vs_pipelined_headline_batch"] = round(
+                    out["pipelined"]["ms_per_step"] / out["batch_512"]["pipelined"]["ms_per_step"], 3)
+            for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
+                if key in out and args.pairs != 512:   # the other candidate modes: the 512-pair step, single stream and ring, and both ratios
+                    ms4096 = out[key]["ms_per_step"]
+                    w5 = Workload(V, args, other, device, seed0, pairs=512)
+                    dt5 = timed_run(w5, args.steps, args.warmup, 1, None, None)
+                    del w5
+                    p4096 = ring_block(V, args, other, device, seed0, args.pairs, args.steps, ms4096)
+                    p512 = ring_block(V, args, other, device, seed0, 512, args.steps, dt5 / args.steps * 1e3)
+                    out[key]["pipelined"] = p4096
+                    out[key]["batch_512"] = {"value": round(512 * args.steps / dt5, 2), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
+                                             "step_time_ratio_vs_headline_batch": round(ms4096 / (dt5 / args.steps * 1e3), 3),
+                                             "pipelined": p512,
+                                             "step_time_ratio_pipelined_vs_pipelined_headline_batch": round(p4096["ms_per_step"] / p512["ms_per_step"], 3)}
         if not args.no_secondary and args.arith != "reference":
             out["reference"] = reference_block(V, args, device, seed0, ring)
         if not args.no_sequences and not args.no_secondary:

@@ -261,10 +261,12 @@ void vors_batch_destroy(vors_batch* b);
 
 /* Throughput mode for a continuous feed of independent batches: a ring of `depth` batch handles, each on its own internal stream.
  * The tail of a step leaves the GPU partly idle (dependent straggler rounds of the dense LM stage, the last workgroups of the per-pair
- * kernel), its body VALU- or bandwidth-bound: with consecutive steps on different streams the GPU fills one with the other (depth 2 on
- * one MI355X, round-4 driver run: +1.7 % dense frame pairs per second — the dense stage's own side lane absorbed most of what the pipeline used
- * to recover; round 3 measured +6 % dense, +12 % coarse-to-fine; bench.py `pipelined_two_streams` reports the current figure). Every step is a plain
- * vors_batch_track_pairs — same results bit for bit.
+ * kernel), its body VALU- or bandwidth-bound: with consecutive steps on different streams the GPU fills one with the other. Measured on one
+ * MI355X (round 6, profiles/r06_stage_times_512_vs_4096.log; bench.py `pipelined` reports the current figures), depth 3 — the optimum; 2 is
+ * within 10 %, 4 and 6 are no better: 4096-pair steps +3 % (dense FUSED), +10 % (coarse-to-fine, DSO), +25-33 % (dense in the default REFERENCE
+ * arithmetic: the straggler tail of its one-wavefront-per-pair kernel); 512-pair steps — BASELINE config 4's share per GPU, which alone leave
+ * most of the chip idle — +20-45 %: the 4096 / 512 step-time ratio goes from 4.3-5.5 to 6.3-7.0 (FUSED) and 5.0-5.3 (REFERENCE). Every step is a
+ * plain vors_batch_track_pairs — same results bit for bit; the price is `depth` workspaces.
  *   submit: the slot's stream first waits for everything enqueued on hip_stream so far (the inputs, and earlier readers of the output
  *           buffers), then runs the step; nothing is synchronised. Buffers as for vors_batch_track_pairs, and they must stay valid
  *           until the step has completed. *ticket (nullable) identifies the step.

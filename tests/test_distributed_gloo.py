@@ -171,6 +171,8 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert abs(sg["value"] - 96 * 3 / (sg["ms_per_step"] * 3e-3)) / sg["value"] < 1e-3    # the fixed batch per step, whatever N
     for blk in (wk, sg):
         assert blk["self_check"]["gathered_blocks_equal_owners"] and blk["self_check"]["ranks"] == 2 and blk["failed_pairs_rank0"] == 0
+        # ... and the same share as a continuous feed through a ring of 3 handles per rank (vors_pipeline_*), gather included
+        assert blk["pipelined"]["ring"] == 3 and blk["pipelined"]["value"] > 0
     assert d["parity_pinned"] in (True, False) and d["parity_pinned_detail"]
 
 
