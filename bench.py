@@ -25,6 +25,12 @@ import os
 import sys
 import time
 
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (ROCm default: 4) in creation order. This process creates
+# many (every dense handle has a side-lane stream, every vors_pipeline ring one per slot): with 4 queues two slots of a ring end up on ONE
+# queue and run one after the other — measured: 512 REFERENCE pairs per step through a ring of 3, 0.61 ms per step with 4 queues, 0.46 with 8
+# (dense: 8.1 vs 5.0 ms). Must be set before the runtime initialises; the single-stream figures (`value`) do not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "visual-odometry-rs_amd"))
@@ -885,6 +891,7 @@ def main():
                             f"({'RCCL over xGMI, one GPU per rank' if args.backend == 'nccl' else 'gloo TEST backend, ranks share ' + str(n_dev) + ' GPU(s)'})"
                             if world > 1 else "1 GPU"),
             "launch": "hipGraph replay" if args.graph else "eager",
+            "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         },
         "roofline": roofline,
         "stages_ms": {"pyramids": round(float(pyr_ms.mean()), 5), "keyframe": round(float(kf_ms.mean()), 5),

@@ -266,7 +266,10 @@ void vors_batch_destroy(vors_batch* b);
  * within 10 %, 4 and 6 are no better: 4096-pair steps +3 % (dense FUSED), +10 % (coarse-to-fine, DSO), +25-33 % (dense in the default REFERENCE
  * arithmetic: the straggler tail of its one-wavefront-per-pair kernel); 512-pair steps — BASELINE config 4's share per GPU, which alone leave
  * most of the chip idle — +20-45 %: the 4096 / 512 step-time ratio goes from 4.3-5.5 to 6.3-7.0 (FUSED) and 5.0-5.3 (REFERENCE). Every step is a
- * plain vors_batch_track_pairs — same results bit for bit; the price is `depth` workspaces.
+ * plain vors_batch_track_pairs — same results bit for bit; the price is `depth` workspaces. NOTE: the HIP runtime maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (ROCm default 4) in creation order; a process that holds other streams besides the ring's (torch, a
+ * dense handle's side lane, a second ring) should start with GPU_MAX_HW_QUEUES=8 in its environment, or two slots can share one queue and
+ * run one after the other (measured: 0.61 instead of 0.46 ms per 512-pair step; bench.py sets it).
  *   submit: the slot's stream first waits for everything enqueued on hip_stream so far (the inputs, and earlier readers of the output
  *           buffers), then runs the step; nothing is synchronised. Buffers as for vors_batch_track_pairs, and they must stay valid
  *           until the step has completed. *ticket (nullable) identifies the step.

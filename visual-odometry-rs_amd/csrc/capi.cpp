@@ -72,6 +72,7 @@ static vors_status build_geom(const vors_config* cfg, int rows, int cols, Geom* 
     g->huber_delta = cfg->huber_delta;
     g->fused_exact_points = getenv("VORS_FUSED_EXACT_POINTS") ? atoi(getenv("VORS_FUSED_EXACT_POINTS")) : VORS_FUSED_EXACT_POINTS_DEFAULT;
     g->fused_exact_step = getenv("VORS_FUSED_EXACT_STEP") ? atoi(getenv("VORS_FUSED_EXACT_STEP")) : 0;
+    g->ref_inflight_x2 = 2;
     g->ref_rank = (getenv("VORS_REF_RANK") && atoi(getenv("VORS_REF_RANK")) == 0) ? 0 : 1;
     g->fused_small_warp = (getenv("VORS_FUSED_SMALL") && std::string(getenv("VORS_FUSED_SMALL")) == "exact") ? 0 : 1;
     g->S0 = rows * cols;
@@ -1097,6 +1098,9 @@ vors_status vors_pipeline_create(int device, const vors_config* cfg, int depth, 
         vors_batch* b = nullptr;
         vors_status st = vors_batch_create_on(device, cfg, max_pairs, rows, cols, &b);
         if (st != VORS_OK) return st;
+        // a slot of a ring shares the chip with its neighbours' steps (engine.h Geom::ref_inflight_x2): measured at 512 pairs per step, ring of 3,
+        // REFERENCE: coarse-to-fine 0.556 ms per step with the lone step's 5 wavefronts per pair, 0.458 with 4; DSO 0.889 / 0.752
+        if (depth >= 2 && !(getenv("VORS_PIPELINE_INFLIGHT") && atoi(getenv("VORS_PIPELINE_INFLIGHT")) == 0)) b->g.ref_inflight_x2 = 3;
         p->slot.push_back(b);
     }
     DeviceGuard on_device(device);

@@ -40,6 +40,10 @@ struct Geom {
     int fused_small_warp;  // candidate-list modes: such a level takes only (u, v) from the reference's warp chain (lm_kernels.hip fused_stage_b<XW>)
     int ref_rank;       // REFERENCE arithmetic, coarse-to-fine: rank the keyframe kernel's staged regions directly (lm_reference.hip); resolved ONCE per
                         // handle from VORS_REF_RANK (development knob) so that the keyframe stage and the sort take the same decision
+    int ref_inflight_x2;  // REFERENCE arithmetic, candidate lists: twice the number of steps whose LM stages share the chip (2 = a step on its own;
+                          // 3 = a slot of a vors_pipeline ring: the LM stage is ~2/3 of a step, so about 1.5 of them overlap). The workgroup size of
+                          // the workgroup-per-pair kernel is chosen for n_pairs x this / 2 RESIDENT pairs (lm_reference.hip refc_waves_per_pair): a
+                          // ring wants the thinner workgroups whose LDS lets the LM kernels of consecutive steps share a CU. The sums do not depend on it
     int wide_loads_ok;  // set per launch: the caller's buffers are 16-byte aligned, so the dense quad source may use wide loads
     // Masked launches of the keyframe stage (vors_trackers: per-sequence keyframe promotion on the device). When sel_list is set, index k
     // of a kernel's pair dimension addresses pair sel_list[k] for k < *sel_count and nothing beyond (device_common.h select_pair).

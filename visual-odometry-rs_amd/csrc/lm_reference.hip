@@ -1241,7 +1241,8 @@ static RefcDevice refc_device() {
     return RefcDevice{cus, (size_t)lds};
 }
 static size_t refc_lds_bytes(int waves) { return (size_t)2 * (waves - 1) * RW_WORDS * sizeof(float) + sizeof(RefcShared); }
-static int refc_waves_per_pair(int n_pairs, bool dense) {
+static int refc_waves_per_pair(int n_pairs, bool dense, int n_launch = -1) {  // n_pairs: pairs resident together; n_launch: pairs of this launch
+    if (n_launch < 0) n_launch = n_pairs;
     const RefcDevice d = refc_device();
     int w = 0;
     for (int cand : {8, 5, 4, 3}) {
@@ -1255,7 +1256,7 @@ static int refc_waves_per_pair(int n_pairs, bool dense) {
     }
     // dense: two producers do not keep up with the chains of 409,600 points (1024 pairs: 20.5 ms per step with 3 wavefronts, 18.9 with 5 in
     // two rounds of workgroups) — five up to 1280 pairs as before
-    if (dense && w < 4 && n_pairs <= 5 * d.cus && refc_lds_bytes(5) <= d.lds_per_cu) w = 5;
+    if (dense && w < 4 && n_launch <= 5 * d.cus && refc_lds_bytes(5) <= d.lds_per_cu) w = 5;
     if (const char* e = getenv("VORS_REF_COOP")) {
         const int v = atoi(e);
         if (v == 0 || (v >= 2 && v <= 8 && refc_lds_bytes(v) <= d.lds_per_cu)) w = v;
@@ -1269,7 +1270,12 @@ void launch_lm_track_reference(const Geom& g, Pyramid cur, Pyramid kf, const uin
     const bool huber = g.huber_delta > 0.f;
     // dense mode: the column-major planes (capi.cpp allocates and fills them for every REFERENCE handle); without them, the gathering source
     const int src = g.mode != VORS_CANDIDATES_DENSE ? REF_SRC_SLIM : (rec.dense_t.recs ? REF_SRC_DENSE_T : REF_SRC_DENSE_ROWMAJOR);
-    const int coop = refc_waves_per_pair(n_pairs, g.mode == VORS_CANDIDATES_DENSE);
+    // (a slot of a vors_pipeline ring: the workgroup size for the pairs that are resident TOGETHER — engine.h Geom::ref_inflight_x2. Measured at
+    // 512 pairs per step through a ring of 3: coarse-to-fine 0.556 -> 0.462 ms per step, DSO 0.889 -> 0.754, dense 6.18 -> 5.53 with 4
+    // wavefronts per pair instead of the lone step's 5)
+    const bool dense = g.mode == VORS_CANDIDATES_DENSE;
+    const int resident = (int)std::min<long long>((long long)n_pairs * std::max(2, g.ref_inflight_x2) / 2, 1 << 30);
+    const int coop = refc_waves_per_pair(resident, dense, n_pairs);
 #define VORS_REF_DISPATCH(KERNEL)                                                                              \
     do {                                                                                                       \
         if (src == REF_SRC_DENSE_T) {                                                                          \
