@@ -923,10 +923,22 @@ def main():
             # the same per-rank share as a continuous feed through a ring of 3 handles (vors_pipeline_*), the all-gather of a step's 8 f32 per
             # pair issued once that step has completed in stream order (two steps behind the submissions); barrier + MAX over ranks as above
             import torch.distributed as dist
-            r = Ring(V, a_k, args.candidates, device, 0x5EED0000 + rank * a_k.pairs, a_k.pairs, 3)
-            pk = torch.zeros((a_k.pairs, 8), dtype=torch.float32, device=device)
-            ga = torch.zeros((world * a_k.pairs, 8), dtype=torch.float32, device=device)
             from vors_amd.distributed import gather_packed
+            # (an extra measurement must never take the run down: the ring and its buffers are set up under a guard, and the ranks agree —
+            # one MIN all-reduce — that everybody has them before anyone enters the collective loop)
+            r = pk = ga = None
+            err = None
+            try:
+                r = Ring(V, a_k, args.candidates, device, 0x5EED0000 + rank * a_k.pairs, a_k.pairs, 3)
+                pk = torch.zeros((a_k.pairs, 8), dtype=torch.float32, device=device)
+                ga = torch.zeros((world * a_k.pairs, 8), dtype=torch.float32, device=device)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                del r, pk, ga
+                return {"ring": 3, "value": None, "error": err or "another rank could not set up its ring"}
 
             def after(i, w):
                 pk[:, :7] = w.poses
