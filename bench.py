@@ -967,108 +967,123 @@ def main():
         out[other]["pipelined"] = pipelined_scaling(a2, other)
         out["config"]["value_is"] = f"`{args.scaling}` (see the `weak` and `strong` blocks; `strong` is BASELINE configs[3] as written)"
         del packed2, gathered2
+    def guarded(key, fn):
+        # Everything after the headline is an EXTRA measurement: one that fails (a box with less memory, a missing tool) is recorded in
+        # `errors` — loudly, in the line — instead of taking the line, and with it `value`, `roofline` and the other blocks, down.
+        try:
+            out[key] = fn()
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("errors", {})[key] = f"{type(e).__name__}: {e}"
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+
     if rank == 0 and world == 1:
-        if not args.no_secondary:
-            # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload, and BASELINE config 4's per-GPU share on 8 GPUs (512)
-            for nb in (256, 512):
-                if args.pairs != nb:
-                    ws = Workload(V, args, args.candidates, device, seed0, pairs=nb)
-                    ws.batch.enable_kernel_timing(ring)
-                    dts = timed_run(ws, args.steps, args.warmup, 1, None, None)
-                    out[f"batch_{nb}"] = {"value": round(nb * args.steps / dts, 2), "unit": "frame-pairs/s", "pairs_per_gpu": nb,
-                                          "ms_per_step": round(dts / args.steps * 1e3, 4),
-                                          "lm_kernel_ms": round(float(ws.batch.kernel_times("lm")[-args.steps:].mean()), 5),
-                                          "step_time_ratio_vs_headline_batch": round((dt / args.steps) / (dts / args.steps), 3)}
-                    del ws
-            # ---- the other candidate modes, each with its own stage times, roofline block (I/O-only = SURVEY's conservative sparse headline,
-            # whole job, LM stage; live PMC traffic), CPU baseline (1 pinned core on a sample of the same pairs) and full-batch parity:
-            # `secondary` = the reference's own selection (coarse-to-fine) when the headline is dense, `dso` = config 3's selector
-            for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
-                if other == args.candidates:
-                    continue
-                w2 = Workload(V, args, other, device, seed0)
-                w2.batch.enable_kernel_timing(ring)
-                dt2 = timed_run(w2, args.steps, args.warmup, 1, None, None)
-                st2 = V.decode_stats(w2.stats)
-                io2, lmb2, lmflat2, ev2, _ = byte_model(st2, args.levels, args.rows, args.cols, other == "dense")
-                lm2 = float(w2.batch.kernel_times("lm")[-args.steps:].mean())
-                kf2 = float(w2.batch.kernel_times("keyframe")[-args.steps:].mean())
-                py2 = float((w2.batch.kernel_times("pyramid_keyframe")[-args.steps:] + w2.batch.kernel_times("pyramid_current")[-args.steps:]).mean())
-                val2 = args.pairs * args.steps / dt2
-                cnt2 = live_counters(args, other) if not args.no_pmc else {}
-                tr2 = cnt2.get("traffic_bytes")
-                lm_bytes2 = lmb2 + 32 * args.pairs
-                out[key] = {
-                    "candidates": {"c2f": "coarse_to_fine (reference selection)", "dense": "dense", "dso": "DSO-style selection (config 3)"}[other],
-                    "value": round(val2, 2), "unit": "frame-pairs/s",
-                    "ms_per_step": round(dt2 / args.steps * 1e3, 4),
-                    "stages_ms": {"pyramids": round(py2, 5), "keyframe": round(kf2, 5), "lm": round(lm2, 5)},
-                    "lm_kernel_ms": round(lm2, 5),
-                    "lm_evals_per_pair": round(ev2, 2),
-                    "roofline": {
-                        "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2), "io_only_frac": round(io2 * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
-                        "whole_job_GBps": round((io2 + lmb2) * args.steps / dt2 / 1e9, 2),
-                        "whole_job_frac": round((io2 + lmb2) * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
-                        "lm_stage_achieved": round(lm_bytes2 / (lm2 * 1e-3) / 1e9, 2), "lm_stage_frac": round(lm_bytes2 / (lm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                        "lm_stage_algorithmic_bytes": lm_bytes2, "traffic": tr2, "traffic_source": cnt2.get("source"),
-                        "traffic_over_algorithmic": (round(tr2 / lm_bytes2, 3) if tr2 else None),
-                        "note": "sparse modes: SURVEY §8(d) takes the I/O-only fraction as the conservative headline (the candidate lists are cache-sized)",
-                    },
-                }
-                if args.cpu_pairs != 0:
-                    out[key]["cpu_baseline"] = cpu_baseline(args, w2, val2, n_override=(48 if other == "dense" else 256) if args.cpu_pairs < 0 else args.cpu_pairs)
-                n_par = parity_sample_sizes(args)[other]
-                if n_par > 0:
-                    pb = parity_block(args, w2, n_par)
-                    if key == "secondary":
-                        parity_secondary = pb
-                    else:
-                        out["parity_dso"] = pb
-                del w2
-            # ---- THROUGHPUT MODE (vors_pipeline_*, the C ABI's ring of batch handles on internal streams): the same steps as a continuous feed,
-            # consecutive steps on consecutive handles — each step is still one full pass over its own batch; step k + 1's pyramids and keyframe
-            # stage run under step k's LM stage and its straggler tail. `value` above stays the single-stream figure (its stage times and
-            # roofline are self-consistent); this is what a deployment that feeds batches back to back gets, and what BASELINE config 4's
-            # per-GPU share (512 pairs) needs: a 512-pair step alone leaves most of the chip idle.
-            single_ms = dt / args.steps * 1e3
-            out["pipelined_two_streams"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=2)
-            out["pipelined"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=3)
-            out["pipelined"]["note"] = ("vors_pipeline_* with a ring of 3 handles (pipelined_two_streams: ring of 2); a step = one full pass over its "
-                                        "own batch; not the headline")
-            if "batch_512" in out and args.pairs != 512:
-                out["batch_512"]["pipelined"] = ring_block(V, args, args.candidates, device, seed0, 512, args.steps, out["batch_512"]["ms_per_step"])
-                out["batch_512"]["step_time_ratio_pipelined_vs_pipelined_headline_batch"] = round(
-                    out["pipelined"]["ms_per_step"] / out["batch_512"]["pipelined"]["ms_per_step"], 3)
-            for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
-                if key in out and args.pairs != 512:   # the other candidate modes: the 512-pair step, single stream and ring, and both ratios
-                    ms4096 = out[key]["ms_per_step"]
-                    w5 = Workload(V, args, other, device, seed0, pairs=512)
-                    dt5 = timed_run(w5, args.steps, args.warmup, 1, None, None)
-                    del w5
-                    p4096 = ring_block(V, args, other, device, seed0, args.pairs, args.steps, ms4096)
-                    p512 = ring_block(V, args, other, device, seed0, 512, args.steps, dt5 / args.steps * 1e3)
-                    out[key]["pipelined"] = p4096
-                    out[key]["batch_512"] = {"value": round(512 * args.steps / dt5, 2), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
-                                             "step_time_ratio_vs_headline_batch": round(ms4096 / (dt5 / args.steps * 1e3), 3),
-                                             "pipelined": p512,
-                                             "step_time_ratio_pipelined_vs_pipelined_headline_batch": round(p4096["ms_per_step"] / p512["ms_per_step"], 3)}
+        try:
+            if not args.no_secondary:
+                # ---- SURVEY §8d batch size: 256 pairs (one per CU) of the same workload, and BASELINE config 4's per-GPU share on 8 GPUs (512)
+                for nb in (256, 512):
+                    if args.pairs != nb:
+                        ws = Workload(V, args, args.candidates, device, seed0, pairs=nb)
+                        ws.batch.enable_kernel_timing(ring)
+                        dts = timed_run(ws, args.steps, args.warmup, 1, None, None)
+                        out[f"batch_{nb}"] = {"value": round(nb * args.steps / dts, 2), "unit": "frame-pairs/s", "pairs_per_gpu": nb,
+                                              "ms_per_step": round(dts / args.steps * 1e3, 4),
+                                              "lm_kernel_ms": round(float(ws.batch.kernel_times("lm")[-args.steps:].mean()), 5),
+                                              "step_time_ratio_vs_headline_batch": round((dt / args.steps) / (dts / args.steps), 3)}
+                        del ws
+                # ---- the other candidate modes, each with its own stage times, roofline block (I/O-only = SURVEY's conservative sparse headline,
+                # whole job, LM stage; live PMC traffic), CPU baseline (1 pinned core on a sample of the same pairs) and full-batch parity:
+                # `secondary` = the reference's own selection (coarse-to-fine) when the headline is dense, `dso` = config 3's selector
+                for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
+                    if other == args.candidates:
+                        continue
+                    w2 = Workload(V, args, other, device, seed0)
+                    w2.batch.enable_kernel_timing(ring)
+                    dt2 = timed_run(w2, args.steps, args.warmup, 1, None, None)
+                    st2 = V.decode_stats(w2.stats)
+                    io2, lmb2, lmflat2, ev2, _ = byte_model(st2, args.levels, args.rows, args.cols, other == "dense")
+                    lm2 = float(w2.batch.kernel_times("lm")[-args.steps:].mean())
+                    kf2 = float(w2.batch.kernel_times("keyframe")[-args.steps:].mean())
+                    py2 = float((w2.batch.kernel_times("pyramid_keyframe")[-args.steps:] + w2.batch.kernel_times("pyramid_current")[-args.steps:]).mean())
+                    val2 = args.pairs * args.steps / dt2
+                    cnt2 = live_counters(args, other) if not args.no_pmc else {}
+                    tr2 = cnt2.get("traffic_bytes")
+                    lm_bytes2 = lmb2 + 32 * args.pairs
+                    out[key] = {
+                        "candidates": {"c2f": "coarse_to_fine (reference selection)", "dense": "dense", "dso": "DSO-style selection (config 3)"}[other],
+                        "value": round(val2, 2), "unit": "frame-pairs/s",
+                        "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                        "stages_ms": {"pyramids": round(py2, 5), "keyframe": round(kf2, 5), "lm": round(lm2, 5)},
+                        "lm_kernel_ms": round(lm2, 5),
+                        "lm_evals_per_pair": round(ev2, 2),
+                        "roofline": {
+                            "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "io_only_GBps": round(io2 * args.steps / dt2 / 1e9, 2), "io_only_frac": round(io2 * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
+                            "whole_job_GBps": round((io2 + lmb2) * args.steps / dt2 / 1e9, 2),
+                            "whole_job_frac": round((io2 + lmb2) * args.steps / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
+                            "lm_stage_achieved": round(lm_bytes2 / (lm2 * 1e-3) / 1e9, 2), "lm_stage_frac": round(lm_bytes2 / (lm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                            "lm_stage_algorithmic_bytes": lm_bytes2, "traffic": tr2, "traffic_source": cnt2.get("source"),
+                            "traffic_over_algorithmic": (round(tr2 / lm_bytes2, 3) if tr2 else None),
+                            "note": "sparse modes: SURVEY §8(d) takes the I/O-only fraction as the conservative headline (the candidate lists are cache-sized)",
+                        },
+                    }
+                    if args.cpu_pairs != 0:
+                        out[key]["cpu_baseline"] = cpu_baseline(args, w2, val2, n_override=(48 if other == "dense" else 256) if args.cpu_pairs < 0 else args.cpu_pairs)
+                    n_par = parity_sample_sizes(args)[other]
+                    if n_par > 0:
+                        pb = parity_block(args, w2, n_par)
+                        if key == "secondary":
+                            parity_secondary = pb
+                        else:
+                            out["parity_dso"] = pb
+                    del w2
+                # ---- THROUGHPUT MODE (vors_pipeline_*, the C ABI's ring of batch handles on internal streams): the same steps as a continuous feed,
+                # consecutive steps on consecutive handles — each step is still one full pass over its own batch; step k + 1's pyramids and keyframe
+                # stage run under step k's LM stage and its straggler tail. `value` above stays the single-stream figure (its stage times and
+                # roofline are self-consistent); this is what a deployment that feeds batches back to back gets, and what BASELINE config 4's
+                # per-GPU share (512 pairs) needs: a 512-pair step alone leaves most of the chip idle.
+                single_ms = dt / args.steps * 1e3
+                out["pipelined_two_streams"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=2)
+                out["pipelined"] = ring_block(V, args, args.candidates, device, seed0, args.pairs, args.steps, single_ms, depth=3)
+                out["pipelined"]["note"] = ("vors_pipeline_* with a ring of 3 handles (pipelined_two_streams: ring of 2); a step = one full pass over its "
+                                            "own batch; not the headline")
+                if "batch_512" in out and args.pairs != 512:
+                    out["batch_512"]["pipelined"] = ring_block(V, args, args.candidates, device, seed0, 512, args.steps, out["batch_512"]["ms_per_step"])
+                    out["batch_512"]["step_time_ratio_pipelined_vs_pipelined_headline_batch"] = round(
+                        out["pipelined"]["ms_per_step"] / out["batch_512"]["pipelined"]["ms_per_step"], 3)
+                for key, other in (("secondary", "c2f" if dense else "dense"), ("dso", "dso")):
+                    if key in out and args.pairs != 512:   # the other candidate modes: the 512-pair step, single stream and ring, and both ratios
+                        ms4096 = out[key]["ms_per_step"]
+                        w5 = Workload(V, args, other, device, seed0, pairs=512)
+                        dt5 = timed_run(w5, args.steps, args.warmup, 1, None, None)
+                        del w5
+                        p4096 = ring_block(V, args, other, device, seed0, args.pairs, args.steps, ms4096)
+                        p512 = ring_block(V, args, other, device, seed0, 512, args.steps, dt5 / args.steps * 1e3)
+                        out[key]["pipelined"] = p4096
+                        out[key]["batch_512"] = {"value": round(512 * args.steps / dt5, 2), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
+                                                 "step_time_ratio_vs_headline_batch": round(ms4096 / (dt5 / args.steps * 1e3), 3),
+                                                 "pipelined": p512,
+                                                 "step_time_ratio_pipelined_vs_pipelined_headline_batch": round(p4096["ms_per_step"] / p512["ms_per_step"], 3)}
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("errors", {})["secondary_legs"] = f"{type(e).__name__}: {e}"
         if not args.no_secondary and args.arith != "reference":
-            out["reference"] = reference_block(V, args, device, seed0, ring)
+            guarded("reference", lambda: reference_block(V, args, device, seed0, ring))
         if not args.no_sequences and not args.no_secondary:
-            out["sequences_64"] = sequences_bench(V, args, device)
-            out["single_tracker"] = single_tracker_bench(V, args, device)
+            guarded("sequences_64", lambda: sequences_bench(V, args, device))
+            guarded("single_tracker", lambda: single_tracker_bench(V, args, device))
         if not args.no_secondary and base_shape and args.huber == 0 and not args.no_config5:
-            out["config5"] = config5_block(V, args, device, ring)
+            guarded("config5", lambda: config5_block(V, args, device, ring))
         if not args.no_secondary and args.parity_pairs != 0 and args.arith != "reference":
             sizes = parity_sample_sizes(args)
-            out["parity_reference"] = reference_parity(V, args, device, seed0, sizes)
+            guarded("parity_reference", lambda: reference_parity(V, args, device, seed0, sizes))
         if args.cpu_pairs != 0:
-            out["cpu_baseline"] = cpu_baseline(args, main_w, value)
+            guarded("cpu_baseline", lambda: cpu_baseline(args, main_w, value))
         n_par = parity_sample_sizes(args)[args.candidates]
         if n_par > 0:
             # the headline arithmetic over a FULL-SIZE sample of the batch the timed steps ran on (+ the same for the secondary workload)
-            out["parity"] = parity_block(args, main_w, n_par)
+            guarded("parity", lambda: parity_block(args, main_w, n_par))
             if parity_secondary is not None:
                 out["parity_secondary"] = parity_secondary
     if rank == 0:

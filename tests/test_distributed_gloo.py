@@ -232,4 +232,7 @@ def test_bench_single_rank_json_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    assert "errors" not in d, d.get("errors")   # (round 6: an extra leg that fails is recorded there instead of taking the line down)
+    assert d["pipelined"]["ring"] == 3 and d["pipelined"]["value"] > 0 and d["parity_pinned"] in (True, False)
+    assert d["config5"]["fused"]["value"] > 0 and d["config5"]["reference"]["parity_sample"]["n_poses_bit_identical"] == d["config5"]["reference"]["parity_sample"]["sample_pairs"]
     assert d["parity"]["status_equal"] and d["parity"]["n_beyond_tol"] <= d["parity"]["n_beyond_tol_oracle_f32_vs_f64_accumulation"] + 1
